@@ -1,0 +1,58 @@
+"""Key-seeded weight / input filler shared by the golden generator and the tests.
+
+TEST INFRASTRUCTURE ONLY (see oracle/transvae_oracle.py header).
+
+Weights are a pure function of (key, shape): the reference model, the oracle
+and the HIP model all ``load_state_dict`` the same dictionary, so the golden
+fixtures hold outputs only (recipe item 1).  Scales are
+chosen so that mu/logvar stay O(1) (the reference's own init overflows,
+SURVEY F8) and so that attention / Conv-FFN branches contribute O(1) to the
+residual stream (at the reference init they are numerically invisible, F9).
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict
+
+import torch
+
+
+def _gen(key: str, salt: int = 0) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(key.encode()) + 7919 * salt) & 0x7FFFFFFF)
+    return g
+
+
+def inv_freq(head_dim: int = 64) -> torch.Tensor:
+    """RoPE2D buffer -- R/transvae/modules/attention.py:125-129."""
+    dpa = head_dim // 2
+    return 1.0 / (10000 ** (torch.arange(0, dpa, 2).float() / dpa))
+
+
+def fill_tensor(key: str, shape, gain: float = 1.0) -> torch.Tensor:
+    shape = tuple(shape)
+    g = _gen(key)
+    if key.endswith("inv_freq"):
+        return inv_freq(shape[0] * 4)
+    if len(shape) == 4:  # conv weight OIHW
+        fan_in = shape[1] * shape[2] * shape[3]
+        return torch.randn(shape, generator=g) * (gain / fan_in ** 0.5)
+    if len(shape) == 2:  # linear weight [out, in]
+        return torch.randn(shape, generator=g) * (gain / shape[1] ** 0.5)
+    if key.endswith(".bias"):
+        return torch.randn(shape, generator=g) * 0.1
+    # 1-D norm scales (GroupNorm / LayerNorm / RMSNorm weights)
+    return 1.0 + 0.1 * torch.randn(shape, generator=g)
+
+
+def fill_state_dict(schema: Dict[str, tuple], gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    return {k: fill_tensor(k, s, gain) for k, s in schema.items()}
+
+
+def rand_input(tag: str, shape, lo: float = 0.0, hi: float = 1.0) -> torch.Tensor:
+    """Uniform [lo,hi) tensor that depends only on (tag, shape)."""
+    return torch.rand(tuple(shape), generator=_gen("input:" + tag)) * (hi - lo) + lo
+
+
+def randn_input(tag: str, shape, std: float = 1.0) -> torch.Tensor:
+    return torch.randn(tuple(shape), generator=_gen("inputn:" + tag)) * std

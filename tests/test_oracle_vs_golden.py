@@ -1,0 +1,197 @@
+"""The oracle (oracle/transvae_oracle.py) against vectors minted from the
+reference's own CPU path (oracle/make_goldens.py).  fp32, tolerance 1e-5
+relative to each tensor's max magnitude.  This is what pins parity: every GPU
+test then compares the HIP path with this oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import filler
+from oracle import transvae_oracle as O
+
+TOL = 1e-5
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def filled(prefix, schema):
+    return {prefix + k: filler.fill_tensor(prefix + k, s).requires_grad_(not k.endswith("inv_freq"))
+            for k, s in schema.items()}
+
+
+def check_module(golden_dir, name, fn, schema, xshape):
+    g = load(golden_dir, f"mod_{name}.npz")
+    p = name + "."
+    sd = filled(p, schema)
+    x = filler.randn_input(p + "x", xshape).requires_grad_(True)
+    y = fn(x, sd, p)
+    gy = filler.randn_input(p + "gy", y.shape)
+    y.backward(gy)
+    assert rel_err(y.detach().numpy(), g["y"]) < TOL
+    assert rel_err(x.grad.numpy(), g["dx"]) < TOL
+    for k in schema:
+        if k.endswith("inv_freq"):
+            continue
+        assert rel_err(sd[p + k].grad.numpy(), g["d:" + k]) < 5 * TOL, k
+
+
+def strip(d, p):
+    return {k[len(p):]: v for k, v in d.items() if k.startswith(p)}
+
+
+def test_resblock(golden_dir):
+    check_module(golden_dir, "resblock", O.res_block, strip(O._res_keys("r.", 64), "r."), (2, 64, 16, 16))
+
+
+def test_rmsnorm(golden_dir):
+    def fn(x, sd, p):
+        B, C, H, W = x.shape
+        t = x.flatten(2).transpose(1, 2)
+        return O.rms_norm_tokens(t, sd[p + "weight"]).transpose(1, 2).reshape(B, C, H, W)
+    check_module(golden_dir, "rmsnorm", fn, {"weight": (128,)}, (2, 128, 8, 8))
+
+
+def _attn_schema(c):
+    return {k[len("a.attn."):]: v for k, v in O._tvb_keys("a.", c, 1.0, 64).items() if k.startswith("a.attn.")}
+
+
+def _attn_fn(x, sd, p):
+    B, C, H, W = x.shape
+    t = x.flatten(2).transpose(1, 2)
+    return O.attention_tokens(t, H, W, sd, p).transpose(1, 2).reshape(B, C, H, W)
+
+
+def test_attention_128(golden_dir):
+    check_module(golden_dir, "attn128", _attn_fn, _attn_schema(128), (2, 128, 8, 8))
+
+
+def test_attention_64_nonsquare(golden_dir):
+    check_module(golden_dir, "attn64", _attn_fn, _attn_schema(64), (1, 64, 16, 12))
+
+
+def test_convffn(golden_dir):
+    schema = {k[len("a.ffn."):]: v for k, v in O._tvb_keys("a.", 128, 1.0, 64).items() if k.startswith("a.ffn.")}
+
+    def fn(x, sd, p):
+        B, C, H, W = x.shape
+        t = x.flatten(2).transpose(1, 2)
+        return O.conv_ffn_tokens(t, H, W, sd, p).transpose(1, 2).reshape(B, C, H, W)
+    check_module(golden_dir, "convffn", fn, schema, (2, 128, 8, 8))
+
+
+def test_transvae_block(golden_dir):
+    check_module(golden_dir, "tvblock", O.transvae_block, strip(O._tvb_keys("t.", 128, 1.0, 64), "t."),
+                 (2, 128, 8, 8))
+
+
+def test_downsample(golden_dir):
+    schema = {"main_path.0.weight": (64, 64, 3, 3), "main_path.0.bias": (64,),
+              "main_path.2.weight": (128, 64, 3, 3), "main_path.2.bias": (128,),
+              "dc_conv.weight": (128, 256, 1, 1), "dc_conv.bias": (128,)}
+    check_module(golden_dir, "down", O.downsample, schema, (2, 64, 16, 16))
+
+
+def test_upsample(golden_dir):
+    schema = {"main_path.1.weight": (64, 128, 3, 3), "main_path.1.bias": (64,),
+              "main_path.3.weight": (64, 64, 3, 3), "main_path.3.bias": (64,),
+              "dc_conv.weight": (256, 128, 1, 1), "dc_conv.bias": (256,)}
+    check_module(golden_dir, "up", O.upsample, schema, (2, 128, 8, 8))
+
+
+@pytest.mark.parametrize("hw", [(4, 6), (16, 16)])
+def test_rope(golden_dir, hw):
+    H, W = hw
+    g = load(golden_dir, "mod_rope.npz")
+    t = filler.randn_input(f"rope.{H}x{W}", (1, 2, H * W, 64)).requires_grad_(True)
+    y = O.rope_apply(t, O.rope_tables(H, W, filler.inv_freq(64)))
+    y.backward(filler.randn_input(f"rope.gy.{H}x{W}", y.shape))
+    assert rel_err(y.detach().numpy(), g[f"y_{H}x{W}"]) < TOL
+    assert rel_err(t.grad.numpy(), g[f"dx_{H}x{W}"]) < TOL
+
+
+def test_rope_is_not_a_rotation():
+    """norms are not preserved; the oracle must reproduce that."""
+    t = filler.randn_input("rope.norm", (1, 1, 24, 64))
+    y = O.rope_apply(t, O.rope_tables(4, 6, filler.inv_freq(64)))
+    ratio = (y.norm(dim=-1) / t.norm(dim=-1)).flatten()
+    assert ratio.min() < 0.999 or ratio.max() > 1.001
+
+
+def test_schema_matches_reference(golden_dir):
+    with open(os.path.join(golden_dir, "state_dict_schemas.json")) as f:
+        ref = json.load(f)
+    assert O.state_dict_schema(O.MICRO, latent_dim=4) == {k: tuple(v) for k, v in ref["micro"].items()}
+    assert list(O.state_dict_schema(O.MICRO, latent_dim=4)) == list(ref["micro"])  # same order too
+    for name in ("tiny_f16d32", "large_f16d32"):
+        mine = O.state_dict_schema(O.variant_config(name.split("_")[0], 16, 32), 32)
+        assert mine == {k: tuple(v) for k, v in ref[name].items()}
+        assert list(mine) == list(ref[name])
+    assert len(ref["large_f16d32"]) == 780  # 754 params + 26 inv_freq buffers
+    with open(os.path.join(golden_dir, "param_counts.json")) as f:
+        counts = json.load(f)
+    assert counts["large_f16d32"] == 1049213827 and counts["tiny_f16d32"] == 81887427
+
+
+def test_micro_model(golden_dir):
+    g = load(golden_dir, "micro_model.npz")
+    cfg = dict(O.MICRO)
+    schema = O.state_dict_schema(cfg, latent_dim=4)
+    sd = {k: filler.fill_tensor(k, s).requires_grad_(not k.endswith("inv_freq")) for k, s in schema.items()}
+    x = filler.rand_input("micro.x", (2, 3, 64, 64))
+    eps = filler.randn_input("micro.eps", (2, 4, 4, 4))
+    z_in = filler.randn_input("micro.z", (2, 4, 4, 4))
+    with torch.no_grad():
+        mu, logvar = O.encode(x, sd, cfg)
+        assert rel_err(mu.numpy(), g["mu"]) < TOL and rel_err(logvar.numpy(), g["logvar"]) < TOL
+        assert rel_err(O.decode(z_in, sd, cfg).numpy(), g["dec_z"]) < TOL
+        assert rel_err(g["decoder_direct"], g["dec_z"]) == 0.0
+    recon, mu, logvar = O.forward(x, sd, cfg, eps)
+    assert rel_err(recon.detach().numpy(), g["recon"]) < TOL
+    loss = O.bench_loss(recon, x, mu, logvar)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    with open(os.path.join(golden_dir, "micro_grads.json")) as f:
+        gs = json.load(f)
+    for k, s in gs.items():
+        gr = sd[k].grad.flatten().double()
+        # biases that feed a GroupNorm have an exactly-zero gradient (rounding noise ~1e-9): absolute floor
+        assert abs(float(gr.norm()) - s["l2"]) <= 2e-4 * s["l2"] + 1e-6, k
+        assert np.abs(gr[:8].numpy() - np.array(s["head"])).max() <= 2e-4 * float(gr.abs().max()) + 1e-7, k
+    for k in g:
+        if k.startswith("g:"):
+            assert rel_err(sd[k[2:]].grad.numpy(), g[k]) < 1e-4, k
+    # the patched copy's clamps are inactive on these weights => same numbers
+    gp = load(golden_dir, "micro_model_patched.npz")
+    rc, mc, lc = O.forward(x, sd, cfg, eps, clamp=True)
+    assert rel_err(rc.detach().numpy(), gp["recon"]) < TOL
+    assert rel_err(mc.detach().numpy(), gp["mu"]) < TOL
+
+
+def test_tiny_config1_forward(golden_dir):
+    """BASELINE config 1 (tiny f16d32, 256x256, fp32): image 0 of the bs4 golden
+    (images are independent through the path, so one image pins it)."""
+    g = load(golden_dir, "tiny_forward.npz")
+    cfg = O.variant_config("tiny", 16, 32)
+    sd = filler.fill_state_dict(O.state_dict_schema(cfg, 32))
+    x = filler.rand_input("tiny.x", (4, 3, 256, 256))[:1]
+    eps = filler.randn_input("tiny.eps", (4, 32, 16, 16))[:1]
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        recon, mu, logvar = O.forward(x, sd, cfg, eps)
+    for nm, t in (("recon", recon), ("mu", mu), ("logvar", logvar)):
+        flat = t[0].flatten().double().numpy()
+        idx = g[f"{nm}.0.idx"]
+        scale = float(g[f"{nm}.0.absmax"])
+        assert np.abs(flat[idx] - g[f"{nm}.0.val"]).max() < 2e-5 * scale, nm
+        assert abs(flat.std(ddof=1) - float(g[f"{nm}.0.std"])) < 1e-4 * float(g[f"{nm}.0.std"]), nm
