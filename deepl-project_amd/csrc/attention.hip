@@ -1,0 +1,487 @@
+// Flash attention for the TransVAE block on gfx950: softmax(q k^T * scale) v, non-causal,
+// head_dim 64, bf16 in/out, fp32 statistics (R/transvae/modules/attention.py:88-92).
+//
+// Data: qkv [B, N, 3, heads, 64] bf16 (the fused QKV projection output, RoPE already applied),
+//       o   [B, N, heads, 64] bf16, lse [B, heads, N] fp32.
+//
+// All three kernels use v_mfma_f32_32x32x16_bf16 and keep the softmax row on the MFMA *lane*:
+//   forward  : S^T = K Q^T (key rows, query lanes)  ->  per-lane online softmax  ->  the
+//              exponentiated accumulator is, as it stands, the B operand of O^T = V^T P^T
+//              (guide section 3, "An accumulator tile as the next MFMA's operand"); V is
+//              read from its row-major LDS tile with ds_read_b64_tr_b16.
+//   dq       : same shape of loop with dS^T in place of P^T and K^T in place of V^T.
+//   dk / dv  : S = Q K^T with the key on the lane; P and dS accumulators are the B operands of
+//              dV^T = dO^T P and dK^T = Q^T dS; Q / dO tiles are read by rows and transposed
+//              from one LDS image.  -LSE and -delta enter as initial accumulators.
+// No atomics and no LDS round trip for P / dS; dq costs a second pass over S (3.5x forward
+// MFMA work for the whole backward instead of 2.5x) -- the trade is recorded in DESIGN.md.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+}
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// LDS tiles are [rows][64] bf16 (128-byte rows, 8 chunks of 16 bytes); physical chunk = c ^ swz(row)
+__device__ __forceinline__ int swz_row(int r) { return (r >> 1) & 7; }          // conflict-free ds_read_b128 rows
+__device__ __forceinline__ int swz_tr(int r) { return ((r >> 1) & 1) << 2; }    // conflict-free transposed reads
+
+// DMA `nrows` rows (multiple of 8) of a [*, ld] matrix starting at row g0 into a swizzled LDS tile.
+template <bool TR>
+__device__ __forceinline__ void stage_rows(char* lds, const bf16* base, int g0, int nvalid, size_t ld, int nrows,
+                                           int wave, int lane, const char* zeros) {
+    const int rsub = lane >> 3, slot = lane & 7;
+    for (int j = wave; j < nrows / 8; j += 4) {
+        const int row = j * 8 + rsub;
+        const int c = slot ^ (TR ? swz_tr(row) : swz_row(row));
+        const int gr = g0 + row;
+        const void* src = (gr < nvalid) ? (const void*)(base + (size_t)gr * ld + c * 8) : (const void*)(zeros + lane * 16);
+        __builtin_amdgcn_global_load_lds(TV_GLB(src), TV_LDS(lds + j * 1024), 16, 0, 0);
+    }
+}
+
+// A operand (32 rows x 16 k) read by rows: lane (row = lane&31, half h) takes 16 bytes at d = 16*st + 8*h
+__device__ __forceinline__ bf16x8 read_rows(const char* tile, int row0, int st, int lane) {
+    const int row = row0 + (lane & 31);
+    const int c = (2 * st + (lane >> 5)) ^ swz_row(row);
+    return *(const bf16x8*)(tile + row * 128 + c * 16);
+}
+
+// A operand = transpose of a row-major tile: rows of the operand are columns d = dblk*32 + (lane&31),
+// element j of lane half h is tile row  r0 + 8*(j>>2) + 4*h + (j&3)   (the k order of an accumulator
+// tile used as B operand).  TR selects the tile's swizzle.
+template <bool TR>
+__device__ __forceinline__ bf16x8 read_cols(const char* tile, int r0, int dblk, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int h = g >> 1;
+    const int chunk = dblk * 4 + (g & 1) * 2 + (pp >> 1);
+    const int ra = r0 + 4 * h + q, rb = ra + 8;
+    const int ca = chunk ^ (TR ? swz_tr(ra) : swz_row(ra));
+    const int cb = chunk ^ (TR ? swz_tr(rb) : swz_row(rb));
+    const bf16x4 lo = lds_tr16(tile + ra * 128 + ca * 16 + (pp & 1) * 8);
+    const bf16x4 hi = lds_tr16(tile + rb * 128 + cb * 16 + (pp & 1) * 8);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// registers 8s..8s+7 of an accumulator tile -> bf16 fragment (B operand of the next MFMA)
+__device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16)a[8 * s + j];
+    return r;
+}
+
+struct AttnArgs {
+    const bf16* qkv;
+    const bf16* o;
+    const bf16* d_o;
+    bf16* out;    // fwd: o ; bwd: dqkv
+    float* lse;
+    float* delta;
+    const char* zeros;
+    int B, N, heads;
+    float scale;
+};
+
+constexpr int KV_TILE = 64 * 128;  // bytes of one [64][64] bf16 tile
+
+// ------------------------------------------------------------------------------------------------
+// forward: block = 4 waves x 32 queries; loops over 64-key blocks (K: row tile, V: tr tile)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K 8 KiB + V 8 KiB)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int C = p.heads * 64;
+    const size_t ld = (size_t)3 * C;
+    const bf16* qbase = p.qkv + (size_t)b * p.N * ld + head * 64;
+    const bf16* kbase = qbase + C;
+    const bf16* vbase = qbase + 2 * C;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qi = q0 + (lane & 31);
+    const int h = lane >> 5;
+    const bool q_ok = qi < p.N;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q_ok) v = *(const bf16x8*)(qbase + (size_t)qi * ld + 16 * st + 8 * h);
+        qf[st] = v;
+    }
+    f32x16 ot[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ot[0][i] = ot[1][i] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const float c2 = p.scale * 1.4426950408889634f;
+    const int nblk = (p.N + 63) / 64;
+
+    stage_rows<false>(smem, kbase, 0, p.N, ld, 64, wave, lane, p.zeros);
+    stage_rows<true>(smem + KV_TILE, vbase, 0, p.N, ld, 64, wave, lane, p.zeros);
+    for (int t = 0; t < nblk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nblk) {
+            char* nb = smem + ((t + 1) & 1) * 2 * KV_TILE;
+            stage_rows<false>(nb, kbase, (t + 1) * 64, p.N, ld, 64, wave, lane, p.zeros);
+            stage_rows<true>(nb + KV_TILE, vbase, (t + 1) * 64, p.N, ld, 64, wave, lane, p.zeros);
+        }
+        const char* kt_ = smem + (t & 1) * 2 * KV_TILE;
+        const char* vt_ = kt_ + KV_TILE;
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s[kt] = mfma32(read_rows(kt_, kt * 32, st, lane), qf[st], s[kt]);
+        }
+        // online softmax over this lane's 32 keys (+ the other half-wave's 32)
+        const int kv0 = t * 64;
+        const bool partial = kv0 + 64 > p.N;
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[kt][r] * c2;
+                if (partial) {
+                    const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= p.N) v = -INFINITY;
+                }
+                s[kt][r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(m, mloc);
+        const float alpha = fexp2(m - mnew);
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fexp2(s[kt][r] - mnew);
+                s[kt][r] = pv;
+                rs += pv;
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = mnew;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            ot[0][i] *= alpha;
+            ot[1][i] *= alpha;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const bf16x8 pf = pack_acc(s[kt], ss);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) ot[db] = mfma32(read_cols<true>(vt_, kt * 32 + 16 * ss, db, lane), pf, ot[db]);
+            }
+    }
+    if (q_ok) {
+        const float inv = 1.0f / l;
+        bf16* orow = p.out + ((size_t)b * p.N + qi) * C + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v = {(bf16)(ot[db][4 * g] * inv), (bf16)(ot[db][4 * g + 1] * inv), (bf16)(ot[db][4 * g + 2] * inv),
+                            (bf16)(ot[db][4 * g + 3] * inv)};
+                *(bf16x4*)(orow + db * 32 + 8 * g + 4 * h) = v;
+            }
+        if (h == 0) p.lse[((size_t)b * p.heads + head) * p.N + qi] = (m + __log2f(l)) * 0.6931471805599453f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// delta[b][head][q] = sum_d dO[q][d] * O[q][d]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p) {
+    const long long total = (long long)p.B * p.N * p.heads * 8;  // 8 lanes per (token, head)
+    const int C = p.heads * 64;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int v = (int)(idx & 7);
+        const long long th = idx >> 3;
+        const int head = (int)(th % p.heads);
+        const long long tok = th / p.heads;  // b*N + n
+        const size_t off = (size_t)tok * C + head * 64 + v * 8;
+        const bf16x8 a = *(const bf16x8*)(p.o + off);
+        const bf16x8 g = *(const bf16x8*)(p.d_o + off);
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf((float)a[e], (float)g[e], acc);
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (v == 0) {
+            const long long bb = tok / p.N;
+            const int n = (int)(tok - bb * p.N);
+            p.delta[((size_t)bb * p.heads + head) * p.N + n] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dq: block = 4 waves x 32 queries, loops over 64-key blocks.  K tile: rows + transposed reads,
+// V tile: rows.   dS^T = P^T o (dP^T - delta) ;  dQ^T = K^T dS^T
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int C = p.heads * 64;
+    const size_t ld = (size_t)3 * C;
+    const bf16* qbase = p.qkv + (size_t)b * p.N * ld + head * 64;
+    const bf16* kbase = qbase + C;
+    const bf16* vbase = qbase + 2 * C;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qi = q0 + (lane & 31);
+    const int h = lane >> 5;
+    const bool q_ok = qi < p.N;
+
+    bf16x8 qf[4], gf[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}, g = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (q_ok) {
+            v = *(const bf16x8*)(qbase + (size_t)qi * ld + 16 * st + 8 * h);
+            g = *(const bf16x8*)(p.d_o + ((size_t)b * p.N + qi) * C + head * 64 + 16 * st + 8 * h);
+        }
+        qf[st] = v;
+        gf[st] = g;
+    }
+    float lse = 0.f, delta = 0.f;
+    if (q_ok) {
+        lse = p.lse[((size_t)b * p.heads + head) * p.N + qi];
+        delta = p.delta[((size_t)b * p.heads + head) * p.N + qi];
+    }
+    const float c2 = p.scale * 1.4426950408889634f;
+    const float s_init = -lse / p.scale;
+    f32x16 dqt[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dqt[0][i] = dqt[1][i] = 0.f;
+    const int nblk = (p.N + 63) / 64;
+
+    stage_rows<false>(smem, kbase, 0, p.N, ld, 64, wave, lane, p.zeros);
+    stage_rows<false>(smem + KV_TILE, vbase, 0, p.N, ld, 64, wave, lane, p.zeros);
+    for (int t = 0; t < nblk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nblk) {
+            char* nb = smem + ((t + 1) & 1) * 2 * KV_TILE;
+            stage_rows<false>(nb, kbase, (t + 1) * 64, p.N, ld, 64, wave, lane, p.zeros);
+            stage_rows<false>(nb + KV_TILE, vbase, (t + 1) * 64, p.N, ld, 64, wave, lane, p.zeros);
+        }
+        const char* kt_ = smem + (t & 1) * 2 * KV_TILE;
+        const char* vt_ = kt_ + KV_TILE;
+        const int kv0 = t * 64;
+        const bool partial = kv0 + 64 > p.N;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s[i] = s_init;
+                dp[i] = -delta;
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                s = mfma32(read_rows(kt_, kt * 32, st, lane), qf[st], s);
+                dp = mfma32(read_rows(vt_, kt * 32, st, lane), gf[st], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = fexp2(s[r] * c2);
+                if (partial) {
+                    const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= p.N) pv = 0.f;
+                }
+                s[r] = pv * dp[r];  // dS^T (without the factor `scale`)
+            }
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const bf16x8 df = pack_acc(s, ss);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) dqt[db] = mfma32(read_cols<false>(kt_, kt * 32 + 16 * ss, db, lane), df, dqt[db]);
+            }
+        }
+    }
+    if (q_ok) {
+        bf16* row = p.out + ((size_t)b * p.N + qi) * ld + head * 64;  // q third of dqkv
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v = {(bf16)(dqt[db][4 * g] * p.scale), (bf16)(dqt[db][4 * g + 1] * p.scale),
+                            (bf16)(dqt[db][4 * g + 2] * p.scale), (bf16)(dqt[db][4 * g + 3] * p.scale)};
+                *(bf16x4*)(row + db * 32 + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dk / dv: block = 4 waves x 32 keys (key on the lane), loops over 32-query tiles.
+// LDS stage: Q tile [32][64] (4 KiB), dO tile [32][64] (4 KiB), lse[32] + delta[32] fp32 (256 B)
+// ------------------------------------------------------------------------------------------------
+constexpr int QT_TILE = 32 * 128;
+constexpr int DKV_STAGE = 2 * QT_TILE + 256;
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int C = p.heads * 64;
+    const size_t ld = (size_t)3 * C;
+    const bf16* qbase = p.qkv + (size_t)b * p.N * ld + head * 64;
+    const bf16* kbase = qbase + C;
+    const bf16* vbase = qbase + 2 * C;
+    const bf16* gbase = p.d_o + (size_t)b * p.N * C + head * 64;
+    const float* lse_b = p.lse + ((size_t)b * p.heads + head) * p.N;
+    const float* del_b = p.delta + ((size_t)b * p.heads + head) * p.N;
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int ki = k0 + (lane & 31);
+    const int h = lane >> 5;
+    const bool k_ok = ki < p.N;
+
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        bf16x8 a = {0, 0, 0, 0, 0, 0, 0, 0}, v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (k_ok) {
+            a = *(const bf16x8*)(kbase + (size_t)ki * ld + 16 * st + 8 * h);
+            v = *(const bf16x8*)(vbase + (size_t)ki * ld + 16 * st + 8 * h);
+        }
+        kf[st] = a;
+        vf[st] = v;
+    }
+    f32x16 dkt[2], dvt[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dkt[0][i] = dkt[1][i] = dvt[0][i] = dvt[1][i] = 0.f;
+    const float c2 = p.scale * 1.4426950408889634f;
+    const float inv_scale = 1.0f / p.scale;
+    const int ntile = (p.N + 31) / 32;
+
+    auto stage = [&](int t, char* sb) {
+        stage_rows<false>(sb, qbase, t * 32, p.N, ld, 32, wave, lane, p.zeros);
+        stage_rows<false>(sb + QT_TILE, gbase, t * 32, p.N, (size_t)C, 32, wave, lane, p.zeros);
+        if (wave == 0) {  // lanes 0-31: lse, lanes 32-63: delta (4-byte LDS-DMA)
+            const int q = t * 32 + (lane & 31);
+            const float* src = (q < p.N) ? ((lane < 32 ? lse_b : del_b) + q) : (const float*)(p.zeros + lane * 4);
+            __builtin_amdgcn_global_load_lds(TV_GLB(src), TV_LDS(sb + 2 * QT_TILE), 4, 0, 0);
+        }
+    };
+
+    stage(0, smem);
+    for (int t = 0; t < ntile; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntile) stage(t + 1, smem + ((t + 1) & 1) * DKV_STAGE);
+        const char* qt_ = smem + (t & 1) * DKV_STAGE;
+        const char* gt_ = qt_ + QT_TILE;
+        const float* st_lse = (const float*)(qt_ + 2 * QT_TILE);
+        const float* st_del = st_lse + 32;
+        f32x16 s, dp;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // accumulator rows (queries) 8g+4h+{0..3}
+            const f32x4 lv = *(const f32x4*)(st_lse + 8 * g + 4 * h);
+            const f32x4 dv = *(const f32x4*)(st_del + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[4 * g + e] = -lv[e] * inv_scale;
+                dp[4 * g + e] = -dv[e];
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            s = mfma32(read_rows(qt_, 0, st, lane), kf[st], s);
+            dp = mfma32(read_rows(gt_, 0, st, lane), vf[st], dp);
+        }
+        // queries beyond N have Q = dO = 0, lse = delta = 0  =>  P = 1, dS = 0, and dO^T P adds 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = fexp2(s[r] * c2);
+            s[r] = pv;
+            dp[r] = pv * dp[r];
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const bf16x8 pf = pack_acc(s, ss);
+            const bf16x8 df = pack_acc(dp, ss);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                dvt[db] = mfma32(read_cols<false>(gt_, 16 * ss, db, lane), pf, dvt[db]);
+                dkt[db] = mfma32(read_cols<false>(qt_, 16 * ss, db, lane), df, dkt[db]);
+            }
+        }
+    }
+    if (k_ok) {
+        bf16* krow = p.out + ((size_t)b * p.N + ki) * ld + C + head * 64;
+        bf16* vrow = krow + C;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 a = {(bf16)(dkt[db][4 * g] * p.scale), (bf16)(dkt[db][4 * g + 1] * p.scale),
+                            (bf16)(dkt[db][4 * g + 2] * p.scale), (bf16)(dkt[db][4 * g + 3] * p.scale)};
+                bf16x4 v = {(bf16)dvt[db][4 * g], (bf16)dvt[db][4 * g + 1], (bf16)dvt[db][4 * g + 2], (bf16)dvt[db][4 * g + 3]};
+                *(bf16x4*)(krow + db * 32 + 8 * g + 4 * h) = a;
+                *(bf16x4*)(vrow + db * 32 + 8 * g + 4 * h) = v;
+            }
+    }
+}
+
+int attn_check(const char* name, int B, int N, int heads, float scale) {
+    if (B <= 0 || N <= 0 || heads <= 0 || !(scale > 0.f) || B > 65535 || heads > 65535) {
+        tv_set_error("%s: bad shape B=%d N=%d heads=%d scale=%g", name, B, N, heads, (double)scale);
+        return TV_ERR_ARG;
+    }
+    return TV_OK;
+}
+
+}  // namespace
+
+extern "C" int tv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int heads, float scale, void* stream) {
+    if (attn_check("tv_attn_fwd", B, N, heads, scale)) return TV_ERR_ARG;
+    TV_CHECK_ARG(qkv && o && lse, "tv_attn_fwd: null pointer");
+    if (tv_init() != TV_OK) return TV_ERR_INIT;
+    AttnArgs a{};
+    a.qkv = (const bf16*)qkv; a.out = (bf16*)o; a.lse = lse; a.zeros = (const char*)tv_zero_page();
+    a.B = B; a.N = N; a.heads = heads; a.scale = scale;
+    dim3 grid(tv_cdiv(N, 128), heads, B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * KV_TILE, (hipStream_t)stream, a);
+    TV_CHECK_LAUNCH("tv_attn_fwd");
+    return TV_OK;
+}
+
+extern "C" int tv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, float* dq_acc,
+                           void* dqkv, int B, int N, int heads, float scale, void* stream) {
+    (void)dq_acc;  // reserved (an atomics-based dq accumulation would use it); may be NULL
+    if (attn_check("tv_attn_bwd", B, N, heads, scale)) return TV_ERR_ARG;
+    TV_CHECK_ARG(qkv && o && d_o && lse && delta && dqkv, "tv_attn_bwd: null pointer");
+    if (tv_init() != TV_OK) return TV_ERR_INIT;
+    AttnArgs a{};
+    a.qkv = (const bf16*)qkv; a.o = (const bf16*)o; a.d_o = (const bf16*)d_o; a.out = (bf16*)dqkv;
+    a.lse = const_cast<float*>(lse); a.delta = delta; a.zeros = (const char*)tv_zero_page();
+    a.B = B; a.N = N; a.heads = heads; a.scale = scale;
+    hipStream_t s = (hipStream_t)stream;
+    const long long tot = (long long)B * N * heads * 8;
+    long long g = (tot + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)g), dim3(256), 0, s, a);
+    dim3 grid(tv_cdiv(N, 128), heads, B);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 4 * KV_TILE, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 2 * DKV_STAGE, s, a);
+    TV_CHECK_LAUNCH("tv_attn_bwd");
+    return TV_OK;
+}

@@ -1,0 +1,107 @@
+// Shared device/host helpers for the TransVAE gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/transvae_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define TV_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
+#define TV_GLB(ptr) ((const __attribute__((address_space(1))) void*)(ptr))
+
+// ---------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------
+void tv_set_error(const char* fmt, ...);
+const void* tv_zero_page();  // >= 4 KiB of device zeros (source for padded LDS-DMA lanes)
+
+#define TV_CHECK_ARG(cond, ...)        \
+    do {                               \
+        if (!(cond)) {                 \
+            tv_set_error(__VA_ARGS__); \
+            return TV_ERR_ARG;         \
+        }                              \
+    } while (0)
+
+#define TV_CHECK_LAUNCH(name)                                                  \
+    do {                                                                       \
+        hipError_t e__ = hipGetLastError();                                    \
+        if (e__ != hipSuccess) {                                               \
+            tv_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return TV_ERR_LAUNCH;                                              \
+        }                                                                      \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// activations (device).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7),
+// i.e. the exact (erf) GELU of the reference to fp32 rounding noise.
+// ---------------------------------------------------------------------------
+#define TV_ACT_NONE 0
+#define TV_ACT_GELU 1
+#define TV_ACT_SILU 2
+
+__device__ __forceinline__ float tv_fast_exp(float x) { return __expf(x); }
+
+// returns erf(|x|) pieces: e = exp(-x^2), poly*e = 1-erf(|x|)
+__device__ __forceinline__ float tv_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = tv_fast_exp(-ax * ax);
+    const float r = fmaf(-p, e, 1.0f);
+    return copysignf(r, x);
+}
+
+__device__ __forceinline__ float tv_gelu(float z) { return 0.5f * z * (1.0f + tv_erf(z * 0.70710678118654752f)); }
+
+// d/dz gelu(z) = Phi(z) + z*phi(z)
+__device__ __forceinline__ float tv_gelu_grad(float z) {
+    const float cdf = 0.5f * (1.0f + tv_erf(z * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * tv_fast_exp(-0.5f * z * z);
+    return fmaf(z, pdf, cdf);
+}
+
+__device__ __forceinline__ float tv_sigmoid(float z) { return __frcp_rn(1.0f + tv_fast_exp(-z)); }
+__device__ __forceinline__ float tv_silu(float z) { return z * tv_sigmoid(z); }
+__device__ __forceinline__ float tv_silu_grad(float z) {
+    const float s = tv_sigmoid(z);
+    return s * fmaf(z, 1.0f - s, 1.0f);
+}
+
+template <int ACT>
+__device__ __forceinline__ float tv_act(float z) {
+    if constexpr (ACT == TV_ACT_GELU) return tv_gelu(z);
+    if constexpr (ACT == TV_ACT_SILU) return tv_silu(z);
+    return z;
+}
+__device__ __forceinline__ float tv_act_grad_rt(int act, float z) {
+    if (act == TV_ACT_GELU) return tv_gelu_grad(z);
+    if (act == TV_ACT_SILU) return tv_silu_grad(z);
+    return 1.0f;
+}
+
+// ---------------------------------------------------------------------------
+// wave / block reductions (wave = 64 lanes)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float tv_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float tv_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int tv_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,394 @@
+// Implicit-GEMM "NT" kernel for gfx950: out[m][n] = sum_k A[m][k] * W[n][k]
+//
+//   m : output pixel (b, oy, ox)           M = batch*h_out*w_out
+//   n : output channel                      N = c_out
+//   k : (ky, kx, ci)                        K = kh*kw*c_in, both operands K-contiguous
+//
+// A rows are gathered on the fly from the NHWC activation tensor (3x3 / 1x1 / 2x2-stride-2
+// taps, stride, nearest-x2 upsample folded into the index, zero-dilation for the data
+// gradient of a stride-2 conv), so one kernel serves nn.Linear, every Conv2d of the path
+// and their data gradients.
+//
+// Structure (cdna_hip_programming.md section 5, "minimum 2-phase"): 128-row tiles, 4 waves,
+// bf16 v_mfma_f32_16x16x32, operands staged global->LDS with 16-byte LDS-DMA
+// (global_load_lds_dwordx4) into two buffers: the loads of K-step t+1 are in flight while
+// K-step t is multiplied; one barrier per K-step.  The LDS image is lane-linear (DMA
+// constraint), bank conflicts are removed by XOR-swizzling the 16-byte chunk index on the
+// SOURCE address and on the ds_read_b128 address (rule 21).
+//
+// The MFMA is issued as D' = W_frag x A_frag^T so that every lane ends up with 4*NF
+// consecutive output channels of one pixel: bias / activation / residual / store work on
+// contiguous channel runs.
+#include "common.h"
+
+namespace {
+
+struct IgemmArgs {
+    const bf16* x;
+    const bf16* w;
+    const float* bias;
+    const bf16* res;
+    bf16* pre;
+    bf16* out;
+    const char* zeros;
+    int M, N, K;
+    int batch, h_in, w_in, c_in, ldx;
+    int h_out, w_out, ldo;
+    int kh, kw, stride, pad, up_shift, dil_mask;
+    int tiles_n;
+    int shuffle;
+};
+
+template <int BK>
+__device__ __forceinline__ int swz_of(int i) {  // i: row index inside a 16-row fragment
+    if constexpr (BK == 64)
+        return (i >> 1) & 7;
+    else
+        return (0x78 >> (2 * ((i >> 2) & 3))) & 3;
+}
+
+template <int BM, int BN, int WGM, int WGN, int BK, int ACT, bool DMA>
+__global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int CPR = BK / 8;     // 16-byte chunks per tile row
+    constexpr int RPI = 64 / CPR;   // tile rows covered by one wave-wide 1 KiB piece
+    constexpr int A_INSTR = BM / RPI, B_INSTR = BN / RPI;
+    constexpr int A_IT = (A_INSTR + NW - 1) / NW, B_IT = (B_INSTR + NW - 1) / NW;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, MF = WTM / 16, NF = WTN / 16;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of 16");
+    static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must fill whole DMA pieces");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tile_n = blockIdx.x % p.tiles_n;
+    const int tile_m = blockIdx.x / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread staging bookkeeping ------------------------------------------------
+    const int srow = lane / CPR;   // row inside a DMA piece
+    const int sslot = lane % CPR;  // physical 16-byte slot inside the row
+    int a_oy[A_IT], a_ox[A_IT], a_pix[A_IT], a_chunk[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int j = it * NW + wave;
+        const int row = j * RPI + srow;
+        const int m = m0 + row;
+        a_chunk[it] = (sslot ^ swz_of<BK>(row & 15)) * 8;  // logical channel offset of my slot
+        if (j < A_INSTR && m < p.M) {
+            const int hw = p.h_out * p.w_out;
+            const int b = m / hw;
+            const int r = m - b * hw;
+            const int oy = r / p.w_out;
+            const int ox = r - oy * p.w_out;
+            a_oy[it] = oy * p.stride - p.pad;
+            a_ox[it] = ox * p.stride - p.pad;
+            a_pix[it] = b * p.h_in * p.w_in;
+        } else {
+            a_oy[it] = -(1 << 28);  // never valid
+            a_ox[it] = 0;
+            a_pix[it] = 0;
+        }
+    }
+    const bf16* b_src[B_IT];
+    bool b_ok[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int j = it * NW + wave;
+        const int row = j * RPI + srow;
+        const int rl = row % WTN;
+        const int fi = ((rl / (4 * NF)) << 2) | (row & 3);
+        const int c = (sslot ^ swz_of<BK>(fi)) * 8;
+        const int n = n0 + row;
+        b_ok[it] = (j < B_INSTR) && (n < p.N);
+        b_src[it] = p.w + (size_t)(b_ok[it] ? n : 0) * p.K + c;
+    }
+
+    // running state of the "next K-step to stage"
+    const int cch = p.c_in / BK;  // channel chunks per tap
+    const int nk = p.kh * p.kw * cch;
+    int st_ky = 0, st_kx = 0, st_ch = 0, st_t = 0;
+    const bf16* a_src[A_IT];
+    bool a_ok[A_IT];
+    const int hv = p.h_in << p.up_shift, wv = p.w_in << p.up_shift;
+
+    auto tap_setup = [&]() {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int uy = a_oy[it] + st_ky, ux = a_ox[it] + st_kx;
+            const bool ok = ((unsigned)uy < (unsigned)hv) && ((unsigned)ux < (unsigned)wv) &&
+                            (((uy | ux) & p.dil_mask) == 0);
+            const int iy = uy >> p.up_shift, ix = ux >> p.up_shift;
+            const int pix = a_pix[it] + iy * p.w_in + ix;
+            a_ok[it] = ok;
+            a_src[it] = p.x + (size_t)(ok ? pix : 0) * p.ldx + a_chunk[it];
+        }
+    };
+    tap_setup();
+
+    bf16x8 a_reg[DMA ? 1 : A_IT], b_reg[DMA ? 1 : B_IT];
+
+    // issue the global loads of K-step st_t (DMA: straight into LDS stage `sbase`)
+    auto stage_issue = [&](char* sbase) {
+        const int koff = st_ch * BK;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int j = it * NW + wave;
+            if (A_INSTR % NW != 0 && j >= A_INSTR) break;
+            if constexpr (DMA) {
+                const void* src = a_ok[it] ? (const void*)(a_src[it] + koff) : (const void*)(p.zeros + lane * 16);
+                __builtin_amdgcn_global_load_lds(TV_GLB(src), TV_LDS(sbase + j * 1024), 16, 0, 0);
+            } else {
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (a_ok[it]) v = *(const bf16x8*)(a_src[it] + koff);
+                a_reg[it] = v;
+            }
+        }
+        const int kb = st_t * BK;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int j = it * NW + wave;
+            if (B_INSTR % NW != 0 && j >= B_INSTR) break;
+            if constexpr (DMA) {
+                const void* src = b_ok[it] ? (const void*)(b_src[it] + kb) : (const void*)(p.zeros + lane * 16);
+                __builtin_amdgcn_global_load_lds(TV_GLB(src), TV_LDS(sbase + A_BYTES + j * 1024), 16, 0, 0);
+            } else {
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (b_ok[it]) v = *(const bf16x8*)(b_src[it] + kb);
+                b_reg[it] = v;
+            }
+        }
+        // advance to the following K-step
+        ++st_t;
+        if (++st_ch == cch) {
+            st_ch = 0;
+            if (++st_kx == p.kw) {
+                st_kx = 0;
+                ++st_ky;
+            }
+            if (st_t < nk) tap_setup();
+        }
+    };
+    // register-staged variant only: park the loaded registers in LDS stage `sbase`
+    auto stage_write = [&](char* sbase) {
+        if constexpr (!DMA) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) {
+                const int j = it * NW + wave;
+                if (A_INSTR % NW != 0 && j >= A_INSTR) break;
+                *(bf16x8*)(sbase + j * 1024 + lane * 16) = a_reg[it];
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) {
+                const int j = it * NW + wave;
+                if (B_INSTR % NW != 0 && j >= B_INSTR) break;
+                *(bf16x8*)(sbase + A_BYTES + j * 1024 + lane * 16) = b_reg[it];
+            }
+        }
+    };
+
+    // ---- fragment addressing -------------------------------------------------------------
+    const int fi = lane & 15, fq = lane >> 4;
+    const int sw = swz_of<BK>(fi);
+    const int a_row_off = (wm * WTM + fi) * (BK * 2);
+    const int b_row_off = A_BYTES + (wn * WTN + (fi >> 2) * (4 * NF) + (fi & 3)) * (BK * 2);
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](const char* sbase) {
+#pragma unroll
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            const int coff = ((kk * 4 + fq) ^ sw) * 16;
+            bf16x8 af[MF], bfr[NF];
+#pragma unroll
+            for (int i = 0; i < MF; ++i) af[i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) bfr[j] = *(const bf16x8*)(sbase + b_row_off + j * 4 * (BK * 2) + coff);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop -------------------------------------------------------------------------
+    if constexpr (DMA) {
+        stage_issue(smem);
+        for (int t = 0; t < nk; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 1 < nk) stage_issue(smem + ((t + 1) & 1) * STAGE);
+            compute(smem + (t & 1) * STAGE);
+        }
+    } else {
+        stage_issue(smem);
+        stage_write(smem);
+        for (int t = 0; t < nk; ++t) {
+            __syncthreads();
+            if (t + 1 < nk) stage_issue(nullptr);
+            compute(smem + (t & 1) * STAGE);
+            if (t + 1 < nk) stage_write(smem + ((t + 1) & 1) * STAGE);
+        }
+    }
+
+    // ---- epilogue: bias -> (save pre-activation) -> activation -> residual -> store --------
+    const int hw = p.h_out * p.w_out;
+    const int cq = p.N >> 2;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + fi;
+        if (m >= p.M) continue;
+        size_t row_base = (size_t)m * p.ldo;
+        int sb = 0, sy = 0, sx = 0;
+        if (p.shuffle) {
+            sb = m / hw;
+            const int r = m - sb * hw;
+            sy = r / p.w_out;
+            sx = r - sy * p.w_out;
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int n = n0 + wn * WTN + fq * (4 * NF) + j * 4;
+            if (n >= p.N) continue;
+            size_t off;
+            if (p.shuffle) {
+                const int qs = n / cq;
+                const int c = n - qs * cq;
+                const size_t pix = ((size_t)sb * (2 * p.h_out) + 2 * sy + (qs >> 1)) * (2 * p.w_out) + 2 * sx + (qs & 1);
+                off = pix * p.ldo + c;
+            } else {
+                off = row_base + n;
+            }
+            f32x4 v = acc[i][j];
+            if (p.bias) {
+                const f32x4 bv = *(const f32x4*)(p.bias + n);
+                v += bv;
+            }
+            if (p.pre) {
+                bf16x4 pv = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *(bf16x4*)(p.pre + off) = pv;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = tv_act<ACT>(v[e]);
+            if (p.res) {
+                const bf16x4 rv = *(const bf16x4*)(p.res + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+            }
+            bf16x4 ov = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4*)(p.out + off) = ov;
+        }
+    }
+}
+
+bool g_use_dma = true;
+
+template <int BM, int BN, int WGM, int WGN, int BK, int ACT>
+int launch_cfg(const IgemmArgs& a, hipStream_t s) {
+    constexpr int STAGE = (BM + BN) * BK * 2;
+    const int tiles_m = (a.M + BM - 1) / BM;
+    dim3 grid((unsigned)(tiles_m * a.tiles_n)), block(WGM * WGN * 64);
+    static bool attr_done = false;
+    if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, ACT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, ACT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        attr_done = true;
+    }
+    if (g_use_dma)
+        hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, ACT, true>), grid, block, 2 * STAGE, s, a);
+    else
+        hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, ACT, false>), grid, block, 2 * STAGE, s, a);
+    return 0;
+}
+
+template <int BK, int ACT>
+int launch_bk(IgemmArgs& a, hipStream_t s) {
+    const int N = a.N;
+    if (N % 192 == 0 && N % 128 != 0) {
+        a.tiles_n = N / 192;
+        return launch_cfg<128, 192, 2, 2, BK, ACT>(a, s);
+    }
+    if (N > 64) {
+        a.tiles_n = (N + 127) / 128;
+        return launch_cfg<128, 128, 2, 2, BK, ACT>(a, s);
+    }
+    if (N > 32) {
+        a.tiles_n = 1;
+        return launch_cfg<128, 64, 2, 2, BK, ACT>(a, s);
+    }
+    a.tiles_n = 1;
+    return launch_cfg<128, 32, 4, 1, BK, ACT>(a, s);
+}
+
+template <int BK>
+int launch_act(IgemmArgs& a, int act, hipStream_t s) {
+    switch (act) {
+        case TV_ACT_NONE: return launch_bk<BK, TV_ACT_NONE>(a, s);
+        case TV_ACT_GELU: return launch_bk<BK, TV_ACT_GELU>(a, s);
+        case TV_ACT_SILU: return launch_bk<BK, TV_ACT_SILU>(a, s);
+    }
+    return -1;
+}
+
+}  // namespace
+
+extern "C" int tv_set_dma(int on) {
+    g_use_dma = on != 0;
+    return 0;
+}
+
+extern "C" int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, const float* bias,
+                           const void* residual, void* pre_act, void* out, void* stream) {
+    TV_CHECK_ARG(d && x && w && out, "tv_igemm_nt: null pointer");
+    TV_CHECK_ARG(d->c_in > 0 && d->c_in % 32 == 0, "tv_igemm_nt: c_in=%d must be a multiple of 32", d->c_in);
+    TV_CHECK_ARG(d->c_out > 0 && d->c_out % 4 == 0, "tv_igemm_nt: c_out=%d must be a multiple of 4", d->c_out);
+    TV_CHECK_ARG(d->ldx >= d->c_in && d->ldx % 8 == 0, "tv_igemm_nt: ldx=%d (c_in=%d) must be >= c_in and a multiple of 8", d->ldx, d->c_in);
+    TV_CHECK_ARG(d->ldo % 4 == 0, "tv_igemm_nt: ldo=%d must be a multiple of 4", d->ldo);
+    TV_CHECK_ARG(d->batch > 0 && d->h_in > 0 && d->w_in > 0 && d->h_out > 0 && d->w_out > 0, "tv_igemm_nt: empty geometry");
+    TV_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "tv_igemm_nt: bad taps");
+    TV_CHECK_ARG((d->up_shift | 1) == 1 && (d->dil_mask | 1) == 1, "tv_igemm_nt: up_shift/dil_mask must be 0 or 1");
+    TV_CHECK_ARG(d->act >= 0 && d->act <= 2, "tv_igemm_nt: unknown activation %d", d->act);
+    const long long M = (long long)d->batch * d->h_out * d->w_out;
+    TV_CHECK_ARG(M < (1ll << 31) && (long long)d->batch * d->h_in * d->w_in < (1ll << 31), "tv_igemm_nt: too many pixels");
+    if (d->store_shuffle) {
+        TV_CHECK_ARG(d->c_out % 16 == 0 && d->ldo >= d->c_out / 4, "tv_igemm_nt: shuffle store needs c_out %% 16 == 0");
+    } else {
+        TV_CHECK_ARG(d->ldo >= d->c_out, "tv_igemm_nt: ldo < c_out");
+    }
+    if (tv_init() != TV_OK) return TV_ERR_INIT;
+
+    IgemmArgs a;
+    a.x = (const bf16*)x;
+    a.w = (const bf16*)w;
+    a.bias = bias;
+    a.res = (const bf16*)residual;
+    a.pre = (bf16*)pre_act;
+    a.out = (bf16*)out;
+    a.zeros = (const char*)tv_zero_page();
+    a.M = (int)M;
+    a.N = d->c_out;
+    a.K = d->kh * d->kw * d->c_in;
+    a.batch = d->batch; a.h_in = d->h_in; a.w_in = d->w_in; a.c_in = d->c_in; a.ldx = d->ldx;
+    a.h_out = d->h_out; a.w_out = d->w_out; a.ldo = d->ldo;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
+    a.up_shift = d->up_shift; a.dil_mask = d->dil_mask;
+    a.tiles_n = 1;
+    a.shuffle = d->store_shuffle;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = (d->c_in % 64 == 0) ? launch_act<64>(a, d->act, s) : launch_act<32>(a, d->act, s);
+    if (rc != 0) {
+        tv_set_error("tv_igemm_nt: no kernel for this configuration");
+        return TV_ERR_ARG;
+    }
+    TV_CHECK_LAUNCH("tv_igemm_nt");
+    return TV_OK;
+}

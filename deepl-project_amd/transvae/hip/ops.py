@@ -1,0 +1,470 @@
+"""torch.autograd wrappers over the C ABI of libtransvae_hip.so.
+
+Every function here launches hand-written gfx950 kernels on the *current* HIP stream through
+raw device pointers; there is no CPU or PyTorch-op fallback -- CPU tensors raise.  Activations
+are bf16 NHWC ([B, H, W, C] contiguous; token matrices are [T, C]); parameters stay fp32 master
+copies owned by the nn.Module and are repacked to bf16 per call (the repack of all 1.05 B
+parameters costs ~2 ms, three orders of magnitude below a train step).
+
+Layer "modes" of :class:`ConvFn` (geometry table in include/transvae_hip.h):
+    linear  nn.Linear / 1x1 conv on a token matrix
+    c3s1    Conv2d 3x3 stride 1 pad 1            (R/transvae/modules/blocks.py:34,37 ...)
+    c3s2    Conv2d 3x3 stride 2 pad 1            (upsample.py:36)
+    c3up    nearest-x2 upsample + Conv2d 3x3     (upsample.py:94-95), upsample never materialised
+    unshuf  pixel_unshuffle(2) + 1x1             (upsample.py:60-61)  == 2x2 / stride-2 conv
+    shuf    1x1 + pixel_shuffle(2)               (upsample.py:121-123) == GEMM with shuffled store
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("transvae.hip: this op only runs on a HIP device (MI355X); there is no CPU fallback")
+
+
+def _act_id(act: Optional[str]) -> int:
+    return {None: L.ACT_NONE, "none": L.ACT_NONE, "gelu": L.ACT_GELU, "silu": L.ACT_SILU}[act]
+
+
+# ---------------------------------------------------------------------------------------------
+# raw calls
+# ---------------------------------------------------------------------------------------------
+def pack_weight(w: torch.Tensor, want_fwd: bool, want_t: bool, flip: bool):
+    """w: fp32 [O, T, I] contiguous -> (bf16 [O,T,I] | None, bf16 [I,T,O] | None)."""
+    O, T, I = w.shape
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    d = torch.empty((O, T, I), dtype=BF16, device=w.device) if want_fwd else None
+    dt = torch.empty((I, T, O), dtype=BF16, device=w.device) if want_t else None
+    lib = L.load()
+    L.check(lib.tv_pack_weight(_p(w), _p(d), _p(dt), O, T, I, int(flip), _stream()), "tv_pack_weight")
+    return d, dt
+
+
+def _desc(**kw) -> L.ConvDesc:
+    d = L.ConvDesc()
+    for k in ("up_shift", "dil_mask", "act", "store_shuffle", "pad"):
+        setattr(d, k, 0)
+    d.stride = 1
+    for k, v in kw.items():
+        setattr(d, k, int(v))
+    return d
+
+
+def igemm(desc: L.ConvDesc, x, w, bias, residual, pre, out):
+    lib = L.load()
+    L.check(lib.tv_igemm_nt(C.byref(desc), _p(x), _p(w), _p(bias), _p(residual), _p(pre), _p(out), _stream()), "tv_igemm_nt")
+
+
+def wgrad(desc: L.ConvDesc, x, gy, dw, dbias):
+    lib = L.load()
+    L.check(lib.tv_wgrad_tn(C.byref(desc), _p(x), _p(gy), _p(dw), _p(dbias), _stream()), "tv_wgrad_tn")
+
+
+_ones_cache = {}
+
+
+def _ones(n: int, device) -> torch.Tensor:
+    key = (device, )
+    t = _ones_cache.get(key)
+    if t is None or t.shape[0] < n:
+        t = torch.ones((n, 8), dtype=BF16, device=device)
+        _ones_cache[key] = t
+    return t
+
+
+# ---------------------------------------------------------------------------------------------
+# convolution / linear
+# ---------------------------------------------------------------------------------------------
+class _Geo:
+    """Shapes of one layer instance, derived from mode + tensor shapes."""
+
+    def __init__(self, mode: str, x: torch.Tensor, w: torch.Tensor):
+        self.mode = mode
+        if mode == "linear":
+            assert x.dim() == 2 and w.dim() == 2
+            self.B, self.H, self.W, self.Cin = x.shape[0], 1, 1, x.shape[1]
+            self.Cout, self.KH, self.KW = w.shape[0], 1, 1
+            self.Ho, self.Wo = 1, 1
+            self.out_shape = (self.B, self.Cout)
+        else:
+            assert x.dim() == 4 and w.dim() == 4, (mode, x.shape, w.shape)
+            self.B, self.H, self.W, self.Cin = x.shape
+            self.Cout, self.KH, self.KW = w.shape[0], w.shape[1], w.shape[2]
+            if mode == "c3s1":
+                self.Ho, self.Wo = self.H, self.W
+            elif mode in ("c3s2", "unshuf"):
+                assert self.H % 2 == 0 and self.W % 2 == 0
+                self.Ho, self.Wo = self.H // 2, self.W // 2
+            elif mode == "c3up":
+                self.Ho, self.Wo = 2 * self.H, 2 * self.W
+            elif mode == "shuf":
+                assert self.KH == 1 and self.KW == 1 and self.Cout % 4 == 0
+                self.Ho, self.Wo = self.H, self.W          # GEMM grid; stored to [B,2H,2W,Cout/4]
+            else:
+                raise ValueError(f"unknown conv mode {mode}")
+            if mode == "shuf":
+                self.out_shape = (self.B, 2 * self.H, 2 * self.W, self.Cout // 4)
+            else:
+                self.out_shape = (self.B, self.Ho, self.Wo, self.Cout)
+        assert w.shape[-1] == self.Cin, (mode, tuple(x.shape), tuple(w.shape))
+        exp_k = {"linear": (1, 1), "c3s1": (3, 3), "c3s2": (3, 3), "c3up": (3, 3), "unshuf": (2, 2), "shuf": (1, 1)}[mode]
+        assert (self.KH, self.KW) == exp_k, (mode, tuple(w.shape))
+
+    def fwd_desc(self, act: int) -> L.ConvDesc:
+        m = self.mode
+        common = dict(batch=self.B, h_in=self.H, w_in=self.W, c_in=self.Cin, ldx=self.Cin,
+                      h_out=self.Ho, w_out=self.Wo, c_out=self.Cout, ldo=self.Cout,
+                      kh=self.KH, kw=self.KW, act=act)
+        if m == "linear":
+            return _desc(**common)
+        if m == "c3s1":
+            return _desc(**common, stride=1, pad=1)
+        if m == "c3s2":
+            return _desc(**common, stride=2, pad=1)
+        if m == "c3up":
+            return _desc(**common, stride=1, pad=1, up_shift=1)
+        if m == "unshuf":
+            return _desc(**common, stride=2, pad=0)
+        if m == "shuf":
+            common["ldo"] = self.Cout // 4
+            return _desc(**common, store_shuffle=1)
+        raise ValueError(m)
+
+
+class ConvFn(torch.autograd.Function):
+    """out = act(conv(x, w) + bias) + residual   on bf16 NHWC activations.
+
+    w is the fp32 master weight already viewed as [Cout, KH, KW, Cin] (or [Cout, Cin] for
+    'linear'); its gradient is returned in the same layout, so the caller's permute / cat /
+    scaling of the nn.Parameter stays ordinary autograd.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, mode: str, act: Optional[str]):
+        _need_gpu(x, w)
+        assert x.dtype == BF16 and x.is_contiguous(), "activations must be contiguous bf16 NHWC"
+        assert w.dtype == torch.float32
+        w = w.contiguous()
+        g = _Geo(mode, x, w)
+        act_id = _act_id(act)
+        wb, _ = pack_weight(w.view(g.Cout, g.KH * g.KW, g.Cin), True, False, False)
+        out = torch.empty(g.out_shape, dtype=BF16, device=x.device)
+        need_pre = act_id != L.ACT_NONE and (x.requires_grad or w.requires_grad)
+        pre = torch.empty_like(out) if need_pre else None
+        if residual is not None:
+            assert residual.shape == out.shape and residual.dtype == BF16 and residual.is_contiguous()
+        if bias is not None:
+            assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == g.Cout
+        igemm(g.fwd_desc(act_id), x, wb, bias, residual, pre, out)
+        ctx.geo, ctx.act_id = g, act_id
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.save_for_backward(x, w, pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, pre = ctx.saved_tensors
+        g: _Geo = ctx.geo
+        lib = L.load()
+        gy = gy.contiguous()
+        assert gy.dtype == BF16
+        gres = gy if ctx.has_res else None
+        if ctx.act_id != L.ACT_NONE:
+            gz = torch.empty_like(gy)
+            L.check(lib.tv_act_bwd(_p(pre), _p(gy), _p(gz), gy.numel(), ctx.act_id, _stream()), "tv_act_bwd")
+        else:
+            gz = gy
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = dw = db = None
+        m = g.mode
+        T = g.KH * g.KW
+        if need_dx:
+            if m == "unshuf":  # GEMM rows n = (dy,dx,c): transpose the flattened [Cout, 4*Cin] matrix
+                _, wt = pack_weight(w.view(g.Cout, 1, T * g.Cin), False, True, False)
+            else:              # [Cin][taps (reversed for 3x3)][Cout]
+                _, wt = pack_weight(w.view(g.Cout, T, g.Cin), False, True, m in ("c3s1", "c3s2", "c3up"))
+            if m == "linear":
+                dx = torch.empty((g.B, g.Cin), dtype=BF16, device=x.device)
+                d = _desc(batch=g.B, h_in=1, w_in=1, c_in=g.Cout, ldx=g.Cout, h_out=1, w_out=1, c_out=g.Cin, ldo=g.Cin, kh=1, kw=1)
+                igemm(d, gz, wt, None, None, None, dx)
+            elif m == "c3s1":
+                dx = torch.empty_like(x)
+                d = _desc(batch=g.B, h_in=g.H, w_in=g.W, c_in=g.Cout, ldx=g.Cout, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
+                          kh=3, kw=3, stride=1, pad=1)
+                igemm(d, gz, wt, None, None, None, dx)
+            elif m == "c3s2":
+                dx = torch.empty_like(x)
+                d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
+                          kh=3, kw=3, stride=1, pad=1, up_shift=1, dil_mask=1)
+                igemm(d, gz, wt, None, None, None, dx)
+            elif m == "c3up":
+                du = torch.empty((g.B, g.Ho, g.Wo, g.Cin), dtype=BF16, device=x.device)
+                d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.Ho, w_out=g.Wo, c_out=g.Cin, ldo=g.Cin,
+                          kh=3, kw=3, stride=1, pad=1)
+                igemm(d, gz, wt, None, None, None, du)
+                dx = torch.empty_like(x)
+                L.check(lib.tv_pool2x2_sum(_p(du), _p(dx), g.B, g.H, g.W, g.Cin, _stream()), "tv_pool2x2_sum")
+            elif m == "unshuf":
+                # dx[b,2oy+dy,2ox+dx,c] = sum_co gz[b,oy,ox,co] W[co,dy,dx,c]  -> GEMM with shuffled store
+                dx = torch.empty_like(x)
+                d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.Ho, w_out=g.Wo, c_out=4 * g.Cin, ldo=g.Cin,
+                          kh=1, kw=1, store_shuffle=1)
+                igemm(d, gz, wt, None, None, None, dx)
+            elif m == "shuf":
+                # dx[p,ci] = sum_{q,c} gz_hi[pix(p,q),c] W[(q,c),ci]  -> 2x2/stride-2 gather conv over gz_hi
+                cq = g.Cout // 4
+                dx = torch.empty_like(x)
+                d = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
+                          kh=2, kw=2, stride=2, pad=0)
+                igemm(d, gz, wt, None, None, None, dx)
+        if need_dw or need_db:
+            db = torch.zeros((g.Cout,), dtype=torch.float32, device=x.device) if need_db else None
+            if m != "shuf":
+                dw = torch.zeros_like(w, memory_format=torch.contiguous_format)
+                wgrad(g.fwd_desc(0), x, gz, dw, db)
+            else:
+                cq = g.Cout // 4
+                d = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
+                          kh=2, kw=2, stride=2, pad=0)
+                dwt = torch.zeros((g.Cin, 2, 2, cq), dtype=torch.float32, device=x.device)
+                wgrad(d, gz, x, dwt, None)
+                dw = dwt.permute(1, 2, 3, 0).reshape(g.Cout, 1, 1, g.Cin).contiguous()
+                if need_db:
+                    d1 = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=8, ldo=8,
+                               kh=2, kw=2, stride=2, pad=0)
+                    tmp = torch.zeros((8, 2, 2, cq), dtype=torch.float32, device=x.device)
+                    wgrad(d1, gz, _ones(g.B * g.H * g.W, x.device), tmp, None)
+                    db = tmp[0].reshape(g.Cout).contiguous()
+            if not need_dw:
+                dw = None
+        return dx, dw, db, gres, None, None
+
+
+def conv(x, w, bias=None, residual=None, mode: str = "c3s1", act: Optional[str] = None):
+    return ConvFn.apply(x, w, bias, residual, mode, act)
+
+
+def linear(x, w, bias=None, residual=None, act: Optional[str] = None):
+    return ConvFn.apply(x, w, bias, residual, "linear", act)
+
+
+# ---------------------------------------------------------------------------------------------
+# GroupNorm + SiLU
+# ---------------------------------------------------------------------------------------------
+class GroupNormSiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups: int, eps: float):
+        _need_gpu(x, gamma, beta)
+        assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+        B, H, W, Cc = x.shape
+        lib = L.load()
+        gamma = gamma.contiguous()
+        beta = beta.contiguous()
+        stats = torch.zeros((B, Cc, 2), dtype=torch.float32, device=x.device)
+        L.check(lib.tv_gn_stats(_p(x), _p(stats), B, H * W, Cc, _stream()), "tv_gn_stats")
+        mr = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        L.check(lib.tv_gn_silu_fwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(mr), _p(y), B, H * W, Cc, groups, eps, _stream()),
+                "tv_gn_silu_fwd")
+        ctx.groups = groups
+        ctx.save_for_backward(x, gamma, beta, mr)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, mr = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        lib = L.load()
+        gy = gy.contiguous()
+        red = torch.zeros((B, Cc, 2), dtype=torch.float32, device=x.device)
+        L.check(lib.tv_gn_silu_bwd_reduce(_p(x), _p(gy), _p(mr), _p(gamma), _p(beta), _p(red), B, H * W, Cc, ctx.groups, _stream()),
+                "tv_gn_silu_bwd_reduce")
+        dx = torch.empty_like(x)
+        dg = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
+        db = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
+        L.check(lib.tv_gn_silu_bwd_apply(_p(x), _p(gy), None, _p(mr), _p(red), _p(gamma), _p(beta), _p(dx), _p(dg), _p(db),
+                                         B, H * W, Cc, ctx.groups, _stream()), "tv_gn_silu_bwd_apply")
+        return dx, dg, db, None, None
+
+
+def group_norm_silu(x, gamma, beta, groups: int = 32, eps: float = 1e-5):
+    return GroupNormSiluFn.apply(x, gamma, beta, groups, eps)
+
+
+# ---------------------------------------------------------------------------------------------
+# token-row norms
+# ---------------------------------------------------------------------------------------------
+class RowNormFn(torch.autograd.Function):
+    """mode 0: x*rsqrt(mean x^2 + eps)           (RMSNorm; its weight is folded into the next GEMM)
+    mode 1: LayerNorm-hat(RMSNorm(x)*w)        (the x-hat shared by norm_q / norm_k / norm_v)"""
+
+    @staticmethod
+    def forward(ctx, x, w, mode: int, eps_rms: float, eps_ln: float):
+        _need_gpu(x, w)
+        assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 2
+        T, Cc = x.shape
+        lib = L.load()
+        if w is not None:
+            w = w.contiguous()
+        y = torch.empty_like(x)
+        L.check(lib.tv_rownorm_fwd(_p(x), _p(w), _p(y), T, Cc, mode, eps_rms, eps_ln, _stream()), "tv_rownorm_fwd")
+        ctx.mode, ctx.eps = mode, (eps_rms, eps_ln)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        T, Cc = x.shape
+        lib = L.load()
+        gy = gy.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.zeros((Cc,), dtype=torch.float32, device=x.device) if ctx.mode == 1 else None
+        L.check(lib.tv_rownorm_bwd(_p(x), _p(w), _p(gy), None, _p(dx), _p(dw), T, Cc, ctx.mode, ctx.eps[0], ctx.eps[1], _stream()),
+                "tv_rownorm_bwd")
+        return dx, dw, None, None, None
+
+
+def rms_hat(x, eps: float = 1e-6):
+    return RowNormFn.apply(x, None, 0, eps, 1e-5)
+
+
+def rms_ln_hat(x, w, eps_rms: float = 1e-6, eps_ln: float = 1e-5):
+    return RowNormFn.apply(x, w, 1, eps_rms, eps_ln)
+
+
+# ---------------------------------------------------------------------------------------------
+# attention (RoPE + flash attention, head_dim 64)
+# ---------------------------------------------------------------------------------------------
+class AttentionFn(torch.autograd.Function):
+    """qkv: [B, N, 3*C] bf16 (q | k | v, each [heads, 64]); returns o [B, N, C].
+
+    RoPE is applied IN PLACE on the q and k thirds of `qkv` (the caller must not reuse the
+    un-rotated projections); the backward applies the adjoint to dq, dk.
+    """
+
+    @staticmethod
+    def forward(ctx, qkv, rope_tab, heads: int, scale: float):
+        _need_gpu(qkv)
+        assert qkv.dtype == BF16 and qkv.is_contiguous() and qkv.dim() == 3
+        B, N, C3 = qkv.shape
+        assert C3 == 3 * heads * 64
+        lib = L.load()
+        if rope_tab is not None:
+            assert rope_tab.dtype == torch.float32 and rope_tab.shape == (N, 4, 32) and rope_tab.is_contiguous()
+            L.check(lib.tv_rope_qk(_p(qkv), _p(rope_tab), B, N, heads, 0, _stream()), "tv_rope_qk")
+        o = torch.empty((B, N, heads * 64), dtype=BF16, device=qkv.device)
+        lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+        L.check(lib.tv_attn_fwd(_p(qkv), _p(o), _p(lse), B, N, heads, scale, _stream()), "tv_attn_fwd")
+        ctx.heads, ctx.scale = heads, scale
+        ctx.save_for_backward(qkv, o, lse, rope_tab)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        qkv, o, lse, rope_tab = ctx.saved_tensors
+        B, N, _ = qkv.shape
+        heads = ctx.heads
+        lib = L.load()
+        go = go.contiguous()
+        delta = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+        dq_acc = torch.zeros((B, N, heads * 64), dtype=torch.float32, device=qkv.device)
+        dqkv = torch.empty_like(qkv)
+        L.check(lib.tv_attn_bwd(_p(qkv), _p(o), _p(go), _p(lse), _p(delta), _p(dq_acc), _p(dqkv), B, N, heads, ctx.scale, _stream()),
+                "tv_attn_bwd")
+        if rope_tab is not None:
+            L.check(lib.tv_rope_qk(_p(dqkv), _p(rope_tab), B, N, heads, 1, _stream()), "tv_rope_qk")
+        return dqkv, None, None, None
+
+
+def attention(qkv, rope_tab, heads: int, scale: float):
+    return AttentionFn.apply(qkv, rope_tab, heads, scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# API-boundary layout conversion (NCHW fp32 <-> NHWC bf16) and the stem's im2col
+# ---------------------------------------------------------------------------------------------
+class ToNhwcFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cpad: int):
+        _need_gpu(x)
+        x = x.float().contiguous()
+        B, Cc, H, W = x.shape
+        y = torch.empty((B, H, W, cpad), dtype=BF16, device=x.device)
+        L.check(L.load().tv_nchw_to_nhwc(_p(x), _p(y), B, Cc, H, W, cpad, _stream()), "tv_nchw_to_nhwc")
+        ctx.C = Cc
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        B, H, W, cpad = gy.shape
+        gx = torch.empty((B, ctx.C, H, W), dtype=torch.float32, device=gy.device)
+        L.check(L.load().tv_nhwc_to_nchw(_p(gy), _p(gx), B, ctx.C, H, W, cpad, _stream()), "tv_nhwc_to_nchw")
+        return gx, None
+
+
+class ToNchwFn(torch.autograd.Function):
+    """x: [B,H,W,Cpad] bf16 -> fp32 [B, C, H, W] taking channels [c0, c0+C)."""
+
+    @staticmethod
+    def forward(ctx, x, c0: int, Cc: int):
+        _need_gpu(x)
+        assert x.dtype == BF16 and x.is_contiguous()
+        B, H, W, cpad = x.shape
+        y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+        src = C.c_void_p(x.data_ptr() + 2 * c0)
+        L.check(L.load().tv_nhwc_to_nchw(src, _p(y), B, Cc, H, W, cpad, _stream()), "tv_nhwc_to_nchw")
+        ctx.c0, ctx.cpad = c0, cpad
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.float().contiguous()
+        B, Cc, H, W = gy.shape
+        if ctx.c0 == 0:
+            gx = torch.empty((B, H, W, ctx.cpad), dtype=BF16, device=gy.device)
+            L.check(L.load().tv_nchw_to_nhwc(_p(gy), _p(gx), B, Cc, H, W, ctx.cpad, _stream()), "tv_nchw_to_nhwc")
+        else:  # channel slice in the middle: convert compactly, then place (tiny tensors: mu / logvar)
+            tmp = torch.empty((B, H, W, Cc), dtype=BF16, device=gy.device)
+            L.check(L.load().tv_nchw_to_nhwc(_p(gy), _p(tmp), B, Cc, H, W, Cc, _stream()), "tv_nchw_to_nhwc")
+            gx = torch.zeros((B, H, W, ctx.cpad), dtype=BF16, device=gy.device)
+            gx[..., ctx.c0:ctx.c0 + Cc] = tmp
+        return gx, None, None
+
+
+def to_nhwc(x, cpad: int):
+    return ToNhwcFn.apply(x, cpad)
+
+
+def to_nchw(x, c0: int, Cc: int):
+    return ToNchwFn.apply(x, c0, Cc)
+
+
+def im2col3x3(x: torch.Tensor, kpad: int) -> torch.Tensor:
+    """NCHW fp32 image -> [B*H*W, kpad] bf16 rows of 3x3 patches ordered (ky,kx,c).  No gradient
+    flows to the image (the stem's input is data)."""
+    _need_gpu(x)
+    x = x.detach().float().contiguous()
+    B, Cc, H, W = x.shape
+    y = torch.empty((B * H * W, kpad), dtype=BF16, device=x.device)
+    L.check(L.load().tv_im2col3x3(_p(x), _p(y), B, Cc, H, W, kpad, _stream()), "tv_im2col3x3")
+    return y

@@ -1,0 +1,158 @@
+/*
+ * transvae_hip.h -- C ABI of libtransvae_hip.so, the gfx950 (MI355X) kernels
+ * behind the TransVAE forward/backward path.
+ *
+ * The reference (benabbouosama/DEEPL-Project, R/ = transvae-implementation/)
+ * has no FFI of its own: its hot path is a Python torch.nn.Module that
+ * dispatches to stock ATen ops.  Each entry point
+ * below therefore names the ATen call site(s) it replaces.  The Python shim in
+ * deepl-project_amd/transvae/hip/ binds these with ctypes and raises
+ * RuntimeError(tv_last_error()) on a non-zero status.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is
+ *     allocated or freed inside, nothing synchronises the device
+ *   - activations are bf16, NHWC (= token-major [B, H*W, C]), fp32 accumulate
+ *   - gradients of parameters and all statistics are fp32
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream)
+ *   - return value: 0 on success, TV_ERR_* otherwise
+ */
+#ifndef TRANSVAE_HIP_H
+#define TRANSVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TV_OK 0
+#define TV_ERR_ARG 1     /* bad shape / unsupported configuration */
+#define TV_ERR_LAUNCH 2  /* HIP reported a launch error */
+#define TV_ERR_INIT 3    /* no device / allocation of the zero page failed */
+
+#define TV_ACT_NONE 0
+#define TV_ACT_GELU 1 /* exact (erf) GELU, R/transvae/modules/conv.py:56,86 */
+#define TV_ACT_SILU 2 /* R/transvae/modules/upsample.py:35,96 */
+
+/* library ------------------------------------------------------------------ */
+int tv_init(void);                 /* allocates the device zero page; idempotent */
+const char* tv_last_error(void);   /* message of the last failing call (thread local) */
+int tv_abi_version(void);
+
+/*
+ * Geometry of one implicit-GEMM convolution / linear layer.
+ *   x   : [batch, h_in, w_in, *] bf16, `ldx` elements between pixels (>= c_in)
+ *   out : [batch, h_out, w_out, c_out] bf16, `ldo` elements between pixels
+ * Virtual input coordinate of output (oy,ox), tap (ky,kx):
+ *     uy = oy*stride + ky - pad ,  valid iff 0 <= uy < (h_in << up_shift)
+ *                                        and (uy & dil_mask) == 0
+ *     iy = uy >> up_shift                      (same for x)
+ *   up_shift=1, dil_mask=0 : conv over a nearest-x2 upsampled input that is never
+ *                            materialised (R/transvae/modules/upsample.py:94-95)
+ *   up_shift=1, dil_mask=1 : zero-dilated input = data-gradient of a stride-2 conv
+ * A linear layer is kh=kw=1, stride=1, pad=0, h=w=1, batch=#tokens.
+ */
+typedef struct tv_conv_desc {
+    int batch, h_in, w_in, c_in, ldx;
+    int h_out, w_out, c_out, ldo;
+    int kh, kw, stride, pad;
+    int up_shift, dil_mask;
+    int act;           /* TV_ACT_* applied after bias, before residual */
+    int store_shuffle; /* 1: pixel_shuffle(2) on store: out is [batch, 2*h_out, 2*w_out, c_out/4],
+                          output column n = (dy*2+dx)*(c_out/4) + c  (upsample.py:121-123) */
+} tv_conv_desc;
+
+/*
+ * out = act(conv(x, w) + bias) + residual        (bf16 MFMA, fp32 accumulate)
+ *   w        : [c_out, kh, kw, c_in] bf16 ("KRSC"; a Linear weight [out,in] is kh=kw=1)
+ *   bias     : [c_out] fp32 or NULL
+ *   residual : like out, or NULL
+ *   pre_act  : like out, receives conv+bias before the activation (for backward), or NULL
+ * Replaces F.conv2d / nn.Linear at R/transvae/modules/blocks.py:34,37, conv.py:39,54-60,65,
+ * attention.py:43-48, upsample.py:33-37,42,93-98,103, the conv_in / conv_out / conv_mu / conv_logvar of models/{encoder,decoder,transvae}.py,
+ * and -- called with rotated/transposed weights -- their data gradients.
+ * Requires c_in % 32 == 0, c_out % 4 == 0, ldx % 8 == 0, ldo % 4 == 0.
+ */
+int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, const float* bias,
+                const void* residual, void* pre_act, void* out, void* stream);
+
+/*
+ * Weight gradient of the same layer (fp32, ACCUMULATED into dw / dbias with atomics):
+ *   dw[co][ky][kx][ci] += sum_p gy[p][co] * x_gathered[p][ky][kx][ci]
+ *   dbias[co]          += sum_p gy[p][co]                       (dbias may be NULL)
+ *   gy : [batch, h_out, w_out, c_out] bf16 with `ldo` between pixels
+ * store_shuffle layers are handled by the caller as the transposed problem (x := the hi-res
+ * gradient gathered with 2x2/stride-2 taps, gy := the layer input), so store_shuffle must be 0.
+ * Requires c_in % 8 == 0, c_out % 8 == 0.
+ * Replaces autograd's conv/linear weight-gradient for the call sites above.
+ */
+int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias,
+                void* stream);
+
+/*
+ * fp32 -> bf16 weight repack.  src: [O, T, I] fp32 (T = kh*kw taps).
+ *   dst   : [O, T, I] bf16 (forward operand)                      or NULL
+ *   dst_t : [I, T, O] bf16 with taps reversed if flip_taps        or NULL
+ *           (the operand of the data-gradient convolution)
+ */
+int tv_pack_weight(const float* src, void* dst, void* dst_t, int O, int T, int I, int flip_taps,
+                   void* stream);
+
+/* GroupNorm(32)+SiLU (R/transvae/modules/blocks.py:33,36,60-65; decoder.py:93,128-129) --------- */
+/* per-(b,channel) sums: stats[b][c][0]=sum x, [1]=sum x^2  (fp32, must be zeroed by the caller) */
+int tv_gn_stats(const void* x, float* stats, int batch, int hw, int C, void* stream);
+/* y = silu(groupnorm(x)); stats from tv_gn_stats; writes mean/rstd per (b,group) to mr[b][G][2] */
+int tv_gn_silu_fwd(const void* x, const float* stats, const float* gamma, const float* beta,
+                   float* mr, void* y, int batch, int hw, int C, int G, float eps, void* stream);
+/* backward pass 1: red[b][c][0] += sum dh, red[b][c][1] += sum dh*xhat   (dh = dy * silu'(h)) */
+int tv_gn_silu_bwd_reduce(const void* x, const void* dy, const float* mr, const float* gamma,
+                          const float* beta, float* red, int batch, int hw, int C, int G,
+                          void* stream);
+/* backward pass 2: dx (+= dres if given); dgamma/dbeta (fp32 [C]) accumulated from red */
+int tv_gn_silu_bwd_apply(const void* x, const void* dy, const void* dres, const float* mr,
+                         const float* red, const float* gamma, const float* beta, void* dx,
+                         float* dgamma, float* dbeta, int batch, int hw, int C, int G, void* stream);
+
+/* Token-wise norms (R/transvae/modules/blocks.py:179-194, attention.py:39-41,71-73) ------------
+ * mode 0: y = x * rsqrt(mean(x^2)+eps_rms)                     (RMSNorm, weight folded downstream)
+ * mode 1: u = x*w*rsqrt(mean(x^2)+eps_rms); y = (u-mean u)*rsqrt(var u + eps_ln)
+ *         (RMSNorm followed by the affine-free LayerNorm shared by norm_q/k/v)
+ * rows: x,y [T, C] bf16; w fp32 [C] (mode 1 only). */
+int tv_rownorm_fwd(const void* x, const float* w, void* y, int T, int C, int mode, float eps_rms,
+                   float eps_ln, void* stream);
+/* dx (+= dres if given) and, mode 1, dw[C] += ...  (fp32 atomics) */
+int tv_rownorm_bwd(const void* x, const float* w, const void* dy, const void* dres, void* dx,
+                   float* dw, int T, int C, int mode, float eps_rms, float eps_ln, void* stream);
+
+/* RoPE (R/transvae/modules/attention.py:132-199), in place on the q and k thirds of
+ * qkv [B, N, 3, heads, 64] bf16.  tab: [N, 4, 32] fp32 = cos1,sin1,cos2,sin2 per pair.
+ * transpose=1 applies the adjoint (backward). */
+int tv_rope_qk(void* qkv, const float* tab, int B, int N, int heads, int transpose, void* stream);
+
+/* softmax(q k^T * scale) v, non-causal, head_dim 64 (attention.py:88-92).
+ * qkv [B,N,3,heads,64] bf16; o [B,N,heads,64] bf16; lse [B,heads,N] fp32 (natural log). */
+int tv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int heads, float scale,
+                void* stream);
+/* dqkv [B,N,3,heads,64] bf16 from do; delta [B,heads,N] fp32 is scratch. */
+int tv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                float* dq_acc, void* dqkv, int B, int N, int heads, float scale, void* stream);
+
+/* elementwise ------------------------------------------------------------------------------- */
+/* dz = dy * act'(z)   (n bf16 elements, n % 8 == 0) */
+int tv_act_bwd(const void* z, const void* dy, void* dz, long long n, int act, void* stream);
+/* a += b (bf16, n % 8 == 0) */
+int tv_add_(void* a, const void* b, long long n, void* stream);
+/* NCHW fp32 [B,C,H,W] -> NHWC bf16 [B,H,W,Cpad] (channels >= C zero-filled) and back */
+int tv_nchw_to_nhwc(const float* src, void* dst, int B, int C, int H, int W, int Cpad, void* stream);
+int tv_nhwc_to_nchw(const void* src, float* dst, int B, int C, int H, int W, int Cpad, void* stream);
+/* 3x3/pad-1 patches of an NCHW fp32 image -> [B*H*W, Kpad] bf16 rows ordered (ky,kx,c), for the
+ * stem conv_in (R/transvae/models/encoder.py:52) */
+int tv_im2col3x3(const float* src, void* dst, int B, int C, int H, int W, int Kpad, void* stream);
+/* dst[b,y,x,c] = sum of the 2x2 block of src[b,2y+dy,2x+dx,c]  (adjoint of nearest x2) */
+int tv_pool2x2_sum(const void* src, void* dst, int B, int H, int W, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRANSVAE_HIP_H */

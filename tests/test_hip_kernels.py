@@ -1,0 +1,280 @@
+"""Kernel-level parity: every C-ABI entry point against a plain PyTorch fp32 computation of the
+same op on the same (bf16-rounded) inputs, run on the host.  `-m gpu` only.
+
+Tolerances (stated per assert): outputs are bf16, so each value carries up to 2^-9 relative
+rounding on top of fp32-accumulated sums of bf16 products; we require
+max|hip - ref| <= 1e-2 * max|ref| (BASELINE's bf16 tier) and usually see ~3e-3.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+def r16(t):
+    return t.to(BF).float()
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def ref_conv(x, w, bias, mode, act=None, residual=None):
+    """x NHWC fp32 (already bf16-rounded), w [Cout,KH,KW,Cin] fp32 (rounded) -> NHWC fp32."""
+    if mode == "linear":
+        y = F.linear(x, w, bias)
+    else:
+        xn = x.permute(0, 3, 1, 2)
+        wn = w.permute(0, 3, 1, 2)
+        if mode == "c3s1":
+            y = F.conv2d(xn, wn, bias, padding=1)
+        elif mode == "c3s2":
+            y = F.conv2d(xn, wn, bias, stride=2, padding=1)
+        elif mode == "c3up":
+            y = F.conv2d(F.interpolate(xn, scale_factor=2, mode="nearest"), wn, bias, padding=1)
+        elif mode == "unshuf":
+            y = F.conv2d(xn, wn, bias, stride=2)
+        elif mode == "shuf":
+            y = F.conv2d(xn, wn, bias)
+            B, C4, H, W = y.shape
+            cq = C4 // 4
+            y = y.view(B, 2, 2, cq, H, W).permute(0, 3, 4, 1, 5, 2).reshape(B, cq, 2 * H, 2 * W)
+        y = y.permute(0, 2, 3, 1)
+    if act == "gelu":
+        y = F.gelu(y)
+    elif act == "silu":
+        y = F.silu(y)
+    if residual is not None:
+        y = y + residual
+    return y
+
+
+CONV_CASES = [
+    # mode, x shape, (Cout,KH,KW), act, residual
+    ("linear", (200, 64), (128,), None, False),
+    ("linear", (130, 96), (192,), "gelu", True),      # BK=32 path, BN=192 tile, M edge
+    ("linear", (256, 192), (32,), None, False),       # BN=32 tile
+    ("linear", (77, 128), (64,), "silu", False),      # BN=64 tile
+    ("linear", (300, 256), (384,), None, True),       # 3 N tiles of 128
+    ("linear", (64, 32), (160,), None, False),        # N edge inside the second 128 tile
+    ("c3s1", (2, 9, 7, 64), (64, 3, 3), None, True),
+    ("c3s1", (1, 16, 16, 192), (192, 3, 3), "gelu", False),
+    ("c3s1", (2, 8, 8, 32), (96, 3, 3), "silu", False),
+    ("c3s2", (2, 12, 8, 64), (128, 3, 3), None, True),
+    ("c3up", (2, 5, 6, 128), (64, 3, 3), None, False),
+    ("unshuf", (2, 8, 12, 64), (128, 2, 2), None, True),
+    ("shuf", (2, 6, 5, 128), (256, 1, 1), None, False),
+]
+
+
+def _mk(mode, xs, ws, seed):
+    Cin = xs[-1]
+    wshape = (ws[0], Cin) if mode == "linear" else (ws[0], ws[1], ws[2], Cin)
+    fan = Cin * (1 if mode == "linear" else ws[1] * ws[2])
+    x = r16(gen(*xs, seed=seed))
+    w = r16(gen(*wshape, seed=seed + 1, scale=fan ** -0.5))
+    b = gen(ws[0], seed=seed + 2, scale=0.1)
+    return x, w, b
+
+
+@pytest.mark.parametrize("dma", [1, 0])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"{c[0]}-{'x'.join(map(str, c[1]))}-{c[2][0]}" for c in CONV_CASES])
+def test_conv_forward_backward(case, dma):
+    from transvae.hip import ops, _lib
+    mode, xs, ws, act, use_res = case
+    _lib.load().tv_set_dma(dma)
+    try:
+        x, w, b = _mk(mode, xs, ws, seed=10 * CONV_CASES.index(case))
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True)
+        y0 = ref_conv(xr, wr, br, mode, act, None)
+        res = r16(gen(*y0.shape, seed=5)) if use_res else None
+        rr = res.clone().requires_grad_(True) if use_res else None
+        yref = ref_conv(xr, wr, br, mode, act, rr)
+        gy = r16(gen(*yref.shape, seed=6))
+        yref.backward(gy)
+
+        xd = x.to(dev(), BF).requires_grad_(True)
+        wd = w.to(dev()).requires_grad_(True)
+        bd = b.to(dev()).requires_grad_(True)
+        rd = res.to(dev(), BF).requires_grad_(True) if use_res else None
+        y = ops.conv(xd, wd, bd, rd, mode=mode, act=act)
+        assert y.dtype == BF and tuple(y.shape) == tuple(yref.shape)
+        assert rel(y, yref) < 1e-2
+        y.backward(gy.to(dev(), BF))
+        torch.cuda.synchronize()
+        assert rel(xd.grad, xr.grad) < 1e-2, "dgrad"
+        assert rel(wd.grad, wr.grad) < 1e-2, "wgrad"
+        assert rel(bd.grad, br.grad) < 1e-2, "bias grad"
+        if use_res:
+            assert rel(rd.grad, rr.grad) < 1e-2
+    finally:
+        _lib.load().tv_set_dma(1)
+
+
+def test_pack_weight():
+    from transvae.hip import ops
+    w = gen(40, 9, 72, seed=3)
+    d, dt = ops.pack_weight(w.to(dev()), True, True, True)
+    assert torch.equal(d.cpu(), w.to(BF))
+    assert torch.equal(dt.cpu(), w.flip(1).permute(2, 1, 0).contiguous().to(BF))
+    _, dt2 = ops.pack_weight(w.to(dev()), False, True, False)
+    assert torch.equal(dt2.cpu(), w.permute(2, 1, 0).contiguous().to(BF))
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (3, 7, 9, 192), (1, 32, 32, 32), (2, 24, 24, 320)])
+def test_groupnorm_silu(shape):
+    from transvae.hip import ops
+    B, H, W, Cc = shape
+    x = r16(gen(*shape, seed=1) * 1.5 + 0.3)
+    ga = 1 + 0.1 * gen(Cc, seed=2)
+    be = 0.1 * gen(Cc, seed=3)
+    xr, gr, br = x.clone().requires_grad_(True), ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    yref = F.silu(F.group_norm(xr.permute(0, 3, 1, 2), 32, gr, br, eps=1e-5)).permute(0, 2, 3, 1)
+    gy = r16(gen(*shape, seed=4))
+    yref.backward(gy)
+    xd = x.to(dev(), BF).requires_grad_(True)
+    gd, bd = ga.to(dev()).requires_grad_(True), be.to(dev()).requires_grad_(True)
+    y = ops.group_norm_silu(xd, gd, bd)
+    assert rel(y, yref) < 1e-2
+    y.backward(gy.to(dev(), BF))
+    assert rel(xd.grad, xr.grad) < 1e-2
+    assert rel(gd.grad, gr.grad) < 1e-2
+    assert rel(bd.grad, br.grad) < 1e-2
+
+
+@pytest.mark.parametrize("T,Cc", [(50, 64), (300, 384), (17, 1536), (9, 2560)])
+def test_rownorm(T, Cc):
+    from transvae.hip import ops
+    x = r16(gen(T, Cc, seed=1) * 2.0)
+    w = 1 + 0.1 * gen(Cc, seed=2)
+    gy = r16(gen(T, Cc, seed=3))
+    # mode 0
+    xr = x.clone().requires_grad_(True)
+    yref = xr * torch.rsqrt((xr * xr).mean(-1, keepdim=True) + 1e-6)
+    yref.backward(gy)
+    xd = x.to(dev(), BF).requires_grad_(True)
+    y = ops.rms_hat(xd)
+    assert rel(y, yref) < 1e-2
+    y.backward(gy.to(dev(), BF))
+    assert rel(xd.grad, xr.grad) < 1e-2
+    # mode 1
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    u = xr * torch.rsqrt((xr * xr).mean(-1, keepdim=True) + 1e-6) * wr
+    yref = F.layer_norm(u, (Cc,), eps=1e-5)
+    yref.backward(gy)
+    xd = x.to(dev(), BF).requires_grad_(True)
+    wd = w.to(dev()).requires_grad_(True)
+    y = ops.rms_ln_hat(xd, wd)
+    assert rel(y, yref) < 1e-2
+    y.backward(gy.to(dev(), BF))
+    assert rel(xd.grad, xr.grad) < 1.5e-2
+    assert rel(wd.grad, wr.grad) < 1e-2
+
+
+def test_layout_and_im2col():
+    from transvae.hip import ops
+    x = gen(2, 3, 10, 12, seed=1)
+    y = ops.to_nhwc(x.to(dev()), 32)
+    ref = torch.zeros(2, 10, 12, 32)
+    ref[..., :3] = x.permute(0, 2, 3, 1)
+    assert torch.equal(y.cpu().float(), r16(ref))
+    t = r16(gen(2, 6, 5, 64, seed=2))
+    z = ops.to_nchw(t.to(dev(), BF), 32, 16)
+    assert torch.equal(z.cpu(), t[..., 32:48].permute(0, 3, 1, 2))
+    col = ops.im2col3x3(x.to(dev()), 32).cpu().float().view(2, 10, 12, 32)
+    pat = F.unfold(x, 3, padding=1).view(2, 3, 9, 10, 12).permute(0, 3, 4, 2, 1).reshape(2, 10, 12, 27)
+    assert torch.equal(col[..., :27], r16(pat)) and float(col[..., 27:].abs().max()) == 0.0
+
+
+def test_unsupported_shape_raises():
+    from transvae.hip import ops
+    x = torch.zeros(4, 40, dtype=BF, device=dev())       # c_in not a multiple of 32
+    w = torch.zeros(32, 40, device=dev())
+    with pytest.raises(RuntimeError, match="c_in"):
+        ops.linear(x, w)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(torch.zeros(4, 64, dtype=BF), torch.zeros(32, 64))
+
+
+def _rope_tab(H, W):
+    from oracle import transvae_oracle as O
+    from oracle import filler
+    c1, s1, c2, s2 = O.rope_tables(H, W, filler.inv_freq(64))
+    return torch.stack([c1, s1, c2, s2], dim=1).contiguous()  # [N,4,32]
+
+
+@pytest.mark.parametrize("H,W,heads", [(4, 6, 2), (16, 16, 1)])
+def test_rope_kernel(H, W, heads):
+    from oracle import transvae_oracle as O
+    from oracle import filler
+    from transvae.hip import ops, _lib
+    import ctypes as C
+    B, N = 2, H * W
+    qkv = r16(gen(B, N, 3, heads, 64, seed=7))
+    tab = _rope_tab(H, W)
+    tabs = O.rope_tables(H, W, filler.inv_freq(64))
+    ref = qkv.clone()
+    for which in (0, 1):
+        ref[:, :, which] = O.rope_apply(qkv[:, :, which].permute(0, 2, 1, 3), tabs).permute(0, 2, 1, 3)
+    d = qkv.to(dev(), BF).contiguous()
+    lib = _lib.load()
+    _lib.check(lib.tv_rope_qk(C.c_void_p(d.data_ptr()), C.c_void_p(tab.to(dev()).data_ptr()), B, N, heads, 0, None))
+    torch.cuda.synchronize()
+    assert rel(d, ref) < 1e-2
+    assert torch.equal(d[:, :, 2].cpu().float(), qkv[:, :, 2])  # v untouched
+    # adjoint: <R x, y> == <x, R^T y>
+    y = r16(gen(B, N, 3, heads, 64, seed=8))
+    dy = y.to(dev(), BF).contiguous()
+    _lib.check(lib.tv_rope_qk(C.c_void_p(dy.data_ptr()), C.c_void_p(tab.to(dev()).data_ptr()), B, N, heads, 1, None))
+    xin = qkv[:, :, :2].clone().requires_grad_(True)   # [B,N,2,h,64]
+    out = O.rope_apply(xin.permute(0, 2, 3, 1, 4), tabs)  # [B,2,h,N,64]
+    out.backward(y[:, :, :2].permute(0, 2, 3, 1, 4))
+    assert rel(dy[:, :, :2], xin.grad) < 1e-2
+    assert torch.equal(dy[:, :, 2].cpu().float(), y[:, :, 2])
+
+
+@pytest.mark.parametrize("B,H,W,heads,rope", [(2, 8, 8, 2, True), (1, 16, 12, 1, True), (2, 4, 4, 3, False),
+                                              (1, 16, 16, 2, True), (1, 15, 20, 1, True), (1, 32, 32, 2, True)])
+def test_attention_fwd_bwd(B, H, W, heads, rope):
+    from oracle import transvae_oracle as O
+    from oracle import filler
+    from transvae.hip import ops
+    N, C = H * W, heads * 64
+    qkv = r16(gen(B, N, 3 * C, seed=11))
+    go = r16(gen(B, N, C, seed=12))
+    scale = 64 ** -0.5
+    x = qkv.clone().requires_grad_(True)
+    q, k, v = [t.view(B, N, heads, 64).transpose(1, 2) for t in x.split(C, dim=-1)]
+    if rope:
+        tabs = O.rope_tables(H, W, filler.inv_freq(64))
+        q, k = O.rope_apply(q, tabs), O.rope_apply(k, tabs)
+    s = (q @ k.transpose(-1, -2)) * scale
+    oref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, N, C)
+    oref.backward(go)
+    xd = qkv.to(dev(), BF).requires_grad_(True)
+    tab = _rope_tab(H, W).to(dev()) if rope else None
+    o = ops.attention(xd.clone(), tab, heads, scale)   # clone: RoPE works in place on its input
+    assert rel(o, oref) < 1e-2
+    o.backward(go.to(dev(), BF))
+    g = xd.grad.cpu().float()
+    for i, nm in enumerate("qkv"):
+        assert rel(g[..., i * C:(i + 1) * C], x.grad[..., i * C:(i + 1) * C]) < 2e-2, f"d{nm}"
