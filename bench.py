@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Train-step throughput of the TransVAE path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimizer step over the GLOBAL batch (256 images, 256x256, TransVAE-Large
+f16d32): forward + backward of every micro-batch, gradient all-reduce (N>1, last micro-batch
+only), clip-norm 1.0, AdamW(lr 1e-4, betas (0.9, 0.95), wd 0) -- R/train.py:557-646,681-687.
+Loss = L1 + 1e-8 KL (the closed-form terms of R/transvae/losses/vae_loss.py; LPIPS/VF need external
+networks and are out of scope).  The global batch is FIXED as N grows ("strong" scaling).
+Synthetic data (torch.rand images) and random fan-in-scaled weights of the exact architecture: the
+reference init overflows to NaN in forward, and no checkpoint exists.
+
+Rank 0 prints ONE JSON line.  `roofline` times the dominant kernel (the 192->192 3x3 implicit-GEMM
+convolution of the 256x256 stages, tv_igemm_nt) live with HIP events on the launch stream;
+`cpu_baseline` times the fp32 CPU oracle (a port of the reference path, pinned to it by golden
+vectors) on a bounded sample: ONE image through the same train step on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "deepl-project_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+TRAIN_GFLOP_PER_IMAGE = {"large": 6187.8, "tiny": 1965.6, "base": 2483.7, "huge": 12883.5, "giant": 22221.6}
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def init_scaled_(model, seed: int = 0):
+    """Fan-in scaled random weights (the rule of oracle/filler.py, drawn on the device)."""
+    g = torch.Generator(device=next(model.parameters()).device)
+    g.manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 4:
+                fan = p.shape[1] * p.shape[2] * p.shape[3]
+                p.copy_(torch.randn(p.shape, generator=g, device=p.device) * fan ** -0.5)
+            elif p.dim() == 2:
+                p.copy_(torch.randn(p.shape, generator=g, device=p.device) * p.shape[1] ** -0.5)
+            elif name.endswith(".bias"):
+                p.copy_(torch.randn(p.shape, generator=g, device=p.device) * 0.1)
+            else:
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=p.device))
+
+
+def time_dominant_kernel(mb: int, res: int, dev):
+    """HIP-event timing of tv_igemm_nt on the stage-0 ResBlock conv (192->192, 3x3, res x res)."""
+    from transvae.hip import ops
+    C = 192
+    x = torch.randn(mb, res, res, C, device=dev).to(torch.bfloat16)
+    w = (torch.randn(C, 9, C, device=dev) * (9 * C) ** -0.5)
+    wb, _ = ops.pack_weight(w, True, False, False)
+    out = torch.empty_like(x)
+    d = ops._desc(batch=mb, h_in=res, w_in=res, c_in=C, ldx=C, h_out=res, w_out=res, c_out=C, ldo=C, kh=3, kw=3, stride=1, pad=1)
+    for _ in range(3):
+        ops.igemm(d, x, wb, None, None, None, out)
+    n = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        ops.igemm(d, x, wb, None, None, None, out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flop = 2.0 * mb * res * res * C * 9 * C
+    return {"bound": "mfma", "kernel": "igemm_nt_kernel<128,192,2,2,64> (conv3x3 192->192 @%dx%d, %d images)" % (res, res, mb),
+            "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
+            "traffic": None}
+
+
+def cpu_baseline(variant: str, res: int, threads: int):
+    """The oracle (CPU restatement of the reference path) on ONE image: fwd + bwd + clip + AdamW."""
+    from oracle import transvae_oracle as O
+    torch.set_num_threads(threads)
+    cfg = O.variant_config(variant, 16, 32)
+    schema = O.state_dict_schema(cfg, 32)
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, s in schema.items():
+        if k.endswith("inv_freq"):
+            sd[k] = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+            continue
+        if len(s) == 4:
+            t = torch.randn(s, generator=g) * (s[1] * s[2] * s[3]) ** -0.5
+        elif len(s) == 2:
+            t = torch.randn(s, generator=g) * s[1] ** -0.5
+        elif k.endswith(".bias"):
+            t = torch.randn(s, generator=g) * 0.1
+        else:
+            t = 1.0 + 0.1 * torch.randn(s, generator=g)
+        sd[k] = t.requires_grad_(True)
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0)
+    x = torch.rand(1, 3, res, res, generator=g)
+    eps = torch.randn(1, 32, res // 16, res // 16, generator=g)
+    t0 = time.time()
+    recon, mu, logvar = O.forward(x, sd, cfg, eps)
+    loss = O.bench_loss(recon, x, mu, logvar.clamp(-30, 20))
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(params, 1.0)
+    opt.step()
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"1 image, TransVAE-{variant} f16d32 {res}x{res}, fp32 oracle fwd+bwd+clip+AdamW, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--variant", default="large")
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--global-batch", type=int, default=256)
+    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the TransVAE path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from transvae import TransVAE
+    from transvae.hip import _lib
+    from transvae.parallel import shard_range, train_step, vae_bench_loss, wrap_ddp
+    _lib.load()  # fails loudly if the HIP library is missing
+
+    torch.manual_seed(0)
+    with torch.device(dev):
+        model = TransVAE(variant=args.variant, compression_ratio=16, latent_dim=32)
+    init_scaled_(model, seed=0)
+    model.train()
+    ddp = wrap_ddp(model, dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
+
+    start, count = shard_range(args.global_batch, world, rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1000 + rank)
+    x = torch.rand(count, 3, args.res, args.res, device=dev, generator=gen)
+    lat = args.res // 16
+
+    def forward_loss(m, xb):
+        eps = torch.randn(xb.shape[0], 32, lat, lat, device=dev, generator=gen)
+        recon, mu, logvar = m(xb, eps=eps)
+        return vae_bench_loss(recon, xb, mu, logvar)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        log(f"{args.variant} f16d32 {args.res}px global batch {args.global_batch} on {world} GPU(s), "
+            f"{count} img/rank in micro-batches of {args.micro_batch}")
+    for i in range(args.warmup):
+        loss = train_step(ddp, opt, x, args.micro_batch, forward_loss, 1.0, args.global_batch)
+        if rank == 0:
+            torch.cuda.synchronize()
+            log(f"warmup {i}: loss {float(loss):.4f}  mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = train_step(ddp, opt, x, args.micro_batch, forward_loss, 1.0, args.global_batch)
+        if rank == 0 and args.steps > 1:
+            log(f"step {i} queued")
+    sync()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt)
+    final_loss = float(loss)
+
+    if rank == 0:
+        ips = args.global_batch * args.steps / dt
+        gf = TRAIN_GFLOP_PER_IMAGE.get(args.variant)
+        out = {
+            "metric": "images/sec train step, TransVAE-Large f16d32 256px bs256",
+            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"TransVAE-{args.variant} f16d32 {args.res}x{args.res} train step "
+                                   f"(fwd+bwd+grad all-reduce+clip+AdamW), global batch {args.global_batch}",
+                       "global_batch": args.global_batch, "micro_batch": args.micro_batch, "parallelism": f"dp{world}",
+                       "weights": "random fan-in scaled", "loss": "L1 + 1e-8 KL"},
+            "final_loss": round(final_loss, 5),
+            "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+        }
+        if gf:
+            out["model_tflops_per_gpu"] = round(ips * gf / 1e3 / world, 1)
+            out["mfma_roofline_frac"] = round(ips * gf / 1e3 / world / PEAK_BF16_TFLOPS, 4)
+        log("timing the dominant kernel")
+        out["roofline"] = time_dominant_kernel(min(args.micro_batch, count), args.res, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle, 1 image) ...")
+            del model, ddp, opt
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args.variant, args.res, max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,16 +15,14 @@ constexpr int GN_THREADS = 256;
 constexpr int GN_PIX_PER_BLOCK = 512;
 
 // ---- GroupNorm: per-(b,c) sum / sum of squares ------------------------------------------------
-__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ stats,
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ part,
                                                               int hw, int C) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_acc = (float*)smem;  // [C][2]
+    float* s_acc = (float*)smem;  // [rows][C][2]
     const int nch = C >> 3;
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * GN_PIX_PER_BLOCK;
     const int p1 = min(hw, p0 + GN_PIX_PER_BLOCK);
-    for (int i = threadIdx.x; i < 2 * C; i += GN_THREADS) s_acc[i] = 0.f;
-    __syncthreads();
     const int rows = GN_THREADS / nch;  // pixel lanes per sweep
     const int chunk = threadIdx.x % nch, prow = threadIdx.x / nch;
     if (prow < rows) {
@@ -43,13 +41,29 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16* __rest
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            atomicAdd(&s_acc[(chunk * 8 + e) * 2 + 0], s[e]);
-            atomicAdd(&s_acc[(chunk * 8 + e) * 2 + 1], q[e]);
+            s_acc[(prow * C + chunk * 8 + e) * 2 + 0] = s[e];
+            s_acc[(prow * C + chunk * 8 + e) * 2 + 1] = q[e];
         }
     }
     __syncthreads();
-    float* dst = stats + (size_t)b * C * 2;
-    for (int i = threadIdx.x; i < 2 * C; i += GN_THREADS) atomicAdd(dst + i, s_acc[i]);
+    // fixed-order sum over the pixel lanes -> this block's partial (no atomics: bit-reproducible)
+    float* dst = part + ((size_t)b * gridDim.x + blockIdx.x) * C * 2;
+    for (int i = threadIdx.x; i < 2 * C; i += GN_THREADS) {
+        float a = 0.f;
+        for (int r = 0; r < rows; ++r) a += s_acc[r * C * 2 + i];
+        dst[i] = a;
+    }
+}
+
+// out[b][i] = sum over blocks of part[b][blk][i], in block order (deterministic)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int n) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* src = part + (size_t)b * nblk * n + i;
+    float a = 0.f;
+    for (int k = 0; k < nblk; ++k) a += src[(size_t)k * n];
+    out[(size_t)b * n + i] = a;
 }
 
 // per-channel scale/shift of image b from the channel sums:  h = x*scale[c] + shift[c]
@@ -113,16 +127,14 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const bf16* __r
 // backward pass 1: red[b][c] += (sum dh, sum dh*xhat),  dh = dy * silu'(h)
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reduce_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                                         const float* __restrict__ mr, const float* __restrict__ gamma,
-                                                                        const float* __restrict__ beta, float* __restrict__ red, int hw,
+                                                                        const float* __restrict__ beta, float* __restrict__ part, int hw,
                                                                         int C, int G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_acc = (float*)smem;  // [C][2]
+    float* s_acc = (float*)smem;  // [rows][C][2]
     const int nch = C >> 3, cpg = C / G;
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * GN_PIX_PER_BLOCK;
     const int p1 = min(hw, p0 + GN_PIX_PER_BLOCK);
-    for (int i = threadIdx.x; i < 2 * C; i += GN_THREADS) s_acc[i] = 0.f;
-    __syncthreads();
     const int rows = GN_THREADS / nch;
     const int chunk = threadIdx.x % nch, prow = threadIdx.x / nch;
     if (prow < rows) {
@@ -151,13 +163,18 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reduce_kernel(const bf
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            atomicAdd(&s_acc[(chunk * 8 + e) * 2 + 0], s[e]);
-            atomicAdd(&s_acc[(chunk * 8 + e) * 2 + 1], q[e]);
+            s_acc[(prow * C + chunk * 8 + e) * 2 + 0] = s[e];
+            s_acc[(prow * C + chunk * 8 + e) * 2 + 1] = q[e];
         }
     }
     __syncthreads();
-    float* dst = red + (size_t)b * C * 2;
-    for (int i = threadIdx.x; i < 2 * C; i += GN_THREADS) atomicAdd(dst + i, s_acc[i]);
+    // fixed-order sum over the pixel lanes -> this block's partial (no atomics: bit-reproducible)
+    float* dst = part + ((size_t)b * gridDim.x + blockIdx.x) * C * 2;
+    for (int i = threadIdx.x; i < 2 * C; i += GN_THREADS) {
+        float a = 0.f;
+        for (int r = 0; r < rows; ++r) a += s_acc[r * C * 2 + i];
+        dst[i] = a;
+    }
 }
 
 // backward pass 2: dx = rstd*(dh*gamma - (S1_g + xhat*S2_g)/n) (+ dres)
@@ -446,11 +463,19 @@ static int gn_check(const char* name, int batch, int hw, int C, int G) {
     return TV_OK;
 }
 
-extern "C" int tv_gn_stats(const void* x, float* stats, int batch, int hw, int C, void* stream) {
+static size_t gn_lds_bytes(int C) { return (size_t)(GN_THREADS / (C >> 3)) * C * 2 * sizeof(float); }
+
+extern "C" long long tv_gn_partial_count(int batch, int hw, int C) {
+    return (long long)batch * tv_cdiv(hw, GN_PIX_PER_BLOCK) * C * 2;
+}
+
+extern "C" int tv_gn_stats(const void* x, float* stats, float* partials, int batch, int hw, int C, void* stream) {
     if (gn_check("tv_gn_stats", batch, hw, C, 1)) return TV_ERR_ARG;
-    TV_CHECK_ARG(x && stats, "tv_gn_stats: null pointer");
+    TV_CHECK_ARG(x && stats && partials, "tv_gn_stats: null pointer");
     dim3 grid(tv_cdiv(hw, GN_PIX_PER_BLOCK), batch);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 2 * C * sizeof(float), (hipStream_t)stream, (const bf16*)x, stats, hw, C);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), gn_lds_bytes(C), (hipStream_t)stream, (const bf16*)x, partials, hw, C);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(tv_cdiv(2 * C, 256), batch), dim3(256), 0, (hipStream_t)stream, (const float*)partials, stats,
+                       (int)grid.x, 2 * C);
     TV_CHECK_LAUNCH("tv_gn_stats");
     return TV_OK;
 }
@@ -467,12 +492,14 @@ extern "C" int tv_gn_silu_fwd(const void* x, const float* stats, const float* ga
 }
 
 extern "C" int tv_gn_silu_bwd_reduce(const void* x, const void* dy, const float* mr, const float* gamma, const float* beta,
-                                     float* red, int batch, int hw, int C, int G, void* stream) {
+                                     float* red, float* partials, int batch, int hw, int C, int G, void* stream) {
     if (gn_check("tv_gn_silu_bwd_reduce", batch, hw, C, G)) return TV_ERR_ARG;
-    TV_CHECK_ARG(x && dy && mr && gamma && beta && red, "tv_gn_silu_bwd_reduce: null pointer");
+    TV_CHECK_ARG(x && dy && mr && gamma && beta && red && partials, "tv_gn_silu_bwd_reduce: null pointer");
     dim3 grid(tv_cdiv(hw, GN_PIX_PER_BLOCK), batch);
-    hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel, grid, dim3(GN_THREADS), 2 * C * sizeof(float), (hipStream_t)stream, (const bf16*)x,
-                       (const bf16*)dy, mr, gamma, beta, red, hw, C, G);
+    hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel, grid, dim3(GN_THREADS), gn_lds_bytes(C), (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)dy, mr, gamma, beta, partials, hw, C, G);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(tv_cdiv(2 * C, 256), batch), dim3(256), 0, (hipStream_t)stream, (const float*)partials, red,
+                       (int)grid.x, 2 * C);
     TV_CHECK_LAUNCH("tv_gn_silu_bwd_reduce");
     return TV_OK;
 }

@@ -278,8 +278,9 @@ class GroupNormSiluFn(torch.autograd.Function):
         lib = L.load()
         gamma = gamma.contiguous()
         beta = beta.contiguous()
-        stats = torch.zeros((B, Cc, 2), dtype=torch.float32, device=x.device)
-        L.check(lib.tv_gn_stats(_p(x), _p(stats), B, H * W, Cc, _stream()), "tv_gn_stats")
+        stats = torch.empty((B, Cc, 2), dtype=torch.float32, device=x.device)
+        part = torch.empty((lib.tv_gn_partial_count(B, H * W, Cc),), dtype=torch.float32, device=x.device)
+        L.check(lib.tv_gn_stats(_p(x), _p(stats), _p(part), B, H * W, Cc, _stream()), "tv_gn_stats")
         mr = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
         L.check(lib.tv_gn_silu_fwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(mr), _p(y), B, H * W, Cc, groups, eps, _stream()),
@@ -294,9 +295,10 @@ class GroupNormSiluFn(torch.autograd.Function):
         B, H, W, Cc = x.shape
         lib = L.load()
         gy = gy.contiguous()
-        red = torch.zeros((B, Cc, 2), dtype=torch.float32, device=x.device)
-        L.check(lib.tv_gn_silu_bwd_reduce(_p(x), _p(gy), _p(mr), _p(gamma), _p(beta), _p(red), B, H * W, Cc, ctx.groups, _stream()),
-                "tv_gn_silu_bwd_reduce")
+        red = torch.empty((B, Cc, 2), dtype=torch.float32, device=x.device)
+        part = torch.empty((lib.tv_gn_partial_count(B, H * W, Cc),), dtype=torch.float32, device=x.device)
+        L.check(lib.tv_gn_silu_bwd_reduce(_p(x), _p(gy), _p(mr), _p(gamma), _p(beta), _p(red), _p(part), B, H * W, Cc, ctx.groups,
+                                          _stream()), "tv_gn_silu_bwd_reduce")
         dx = torch.empty_like(x)
         dg = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
         db = torch.zeros((Cc,), dtype=torch.float32, device=x.device)

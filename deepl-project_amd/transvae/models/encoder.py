@@ -1,0 +1,75 @@
+"""TransVAE encoder on the HIP path (interface mirror of R/transvae/models/encoder.py:31-126).
+
+conv_in -> [ResBlocks]x2 stages -> [TransVAEBlocks] for the remaining stages, a Downsample
+between stages.  Activations stay bf16 NHWC from the stem to the last block; the stem reads the
+NCHW fp32 image directly (im2col to K=32, then one GEMM).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.checkpoint
+
+from ..hip import ops
+from ..modules.blocks import ResBlock, TransVAEBlock
+from ..modules.upsample import Downsample
+
+
+class TransVAEEncoder(nn.Module):
+    NUM_CNN_STAGES = 2  # hard-coded in the reference (encoder.py:60)
+
+    def __init__(self, input_channels: int = 3, latent_dim: int = 32, depths: List[int] = (3, 3, 3, 4, 6),
+                 base_dims: List[int] = (192, 192, 384, 768, 1536), compression_ratio: int = 16, mlp_ratio: float = 1.0,
+                 head_dim: int = 64, use_rope: bool = True, use_conv_ffn: bool = True, use_dc_path: bool = True):
+        super().__init__()
+        depths, base_dims = list(depths), list(base_dims)
+        self.num_stages = len(depths)
+        self.depths, self.base_dims, self.compression_ratio = depths, base_dims, compression_ratio
+        self.input_channels = input_channels
+        self.conv_in = nn.Conv2d(input_channels, base_dims[0], 3, padding=1)
+        self.stages = nn.ModuleList()
+        self.downsamples = nn.ModuleList()
+        for i, (depth, dim) in enumerate(zip(depths, base_dims)):
+            if i < self.NUM_CNN_STAGES:
+                blocks = [ResBlock(dim, dim) for _ in range(depth)]
+            else:
+                blocks = [TransVAEBlock(dim=dim, mlp_ratio=mlp_ratio, head_dim=head_dim, use_rope=use_rope,
+                                        use_conv_ffn=use_conv_ffn) for _ in range(depth)]
+            self.stages.append(nn.ModuleList(blocks))
+            if i < self.num_stages - 1:
+                self.downsamples.append(Downsample(dim, base_dims[i + 1], use_dc_path=use_dc_path))
+        self.gradient_checkpointing = False
+
+    def enable_gradient_checkpointing(self):
+        self.gradient_checkpointing = True
+
+    def _stem(self, x: torch.Tensor) -> torch.Tensor:
+        B, C, H, W = x.shape
+        k = 9 * C
+        kpad = (k + 31) // 32 * 32
+        cols = ops.im2col3x3(x, kpad)                                   # [B*H*W, kpad], (ky,kx,c) order
+        w = F.pad(self.conv_in.weight.permute(0, 2, 3, 1).reshape(-1, k), (0, kpad - k))
+        return ops.linear(cols, w, self.conv_in.bias).view(B, H, W, -1)
+
+    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [B, C, H, W] image (any float dtype) -> [B, H/f, W/f, C_last] bf16."""
+        f = 2 ** (self.num_stages - 1)
+        if x.shape[-1] % f or x.shape[-2] % f:
+            raise RuntimeError(f"input {tuple(x.shape[-2:])} must be divisible by {f}")
+        h = self._stem(x)
+        for i, stage in enumerate(self.stages):
+            for block in stage:
+                if self.gradient_checkpointing and self.training:
+                    h = torch.utils.checkpoint.checkpoint(block.forward_nhwc, h, use_reentrant=False)
+                else:
+                    h = block.forward_nhwc(h)
+            if i < len(self.downsamples):
+                h = self.downsamples[i].forward_nhwc(h)
+        return h
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        h = self.forward_nhwc(x)
+        return ops.to_nchw(h, 0, h.shape[-1])

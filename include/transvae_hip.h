@@ -100,15 +100,19 @@ int tv_pack_weight(const float* src, void* dst, void* dst_t, int O, int T, int I
                    void* stream);
 
 /* GroupNorm(32)+SiLU (R/transvae/modules/blocks.py:33,36,60-65; decoder.py:93,128-129) --------- */
-/* per-(b,channel) sums: stats[b][c][0]=sum x, [1]=sum x^2  (fp32, must be zeroed by the caller) */
-int tv_gn_stats(const void* x, float* stats, int batch, int hw, int C, void* stream);
+/* Reductions over all pixels of an image span workgroups: each block writes a partial sum and a
+ * finalize kernel adds the partials in block order (no atomics => bit-reproducible).  `partials`
+ * is scratch of tv_gn_partial_count(batch, hw, C) floats. */
+long long tv_gn_partial_count(int batch, int hw, int C);
+/* per-(b,channel) sums: stats[b][c][0]=sum x, [1]=sum x^2  (fp32) */
+int tv_gn_stats(const void* x, float* stats, float* partials, int batch, int hw, int C, void* stream);
 /* y = silu(groupnorm(x)); stats from tv_gn_stats; writes mean/rstd per (b,group) to mr[b][G][2] */
 int tv_gn_silu_fwd(const void* x, const float* stats, const float* gamma, const float* beta,
                    float* mr, void* y, int batch, int hw, int C, int G, float eps, void* stream);
-/* backward pass 1: red[b][c][0] += sum dh, red[b][c][1] += sum dh*xhat   (dh = dy * silu'(h)) */
+/* backward pass 1: red[b][c][0] = sum dh, red[b][c][1] = sum dh*xhat   (dh = dy * silu'(h)) */
 int tv_gn_silu_bwd_reduce(const void* x, const void* dy, const float* mr, const float* gamma,
-                          const float* beta, float* red, int batch, int hw, int C, int G,
-                          void* stream);
+                          const float* beta, float* red, float* partials, int batch, int hw, int C,
+                          int G, void* stream);
 /* backward pass 2: dx (+= dres if given); dgamma/dbeta (fp32 [C]) accumulated from red */
 int tv_gn_silu_bwd_apply(const void* x, const void* dy, const void* dres, const float* mr,
                          const float* red, const float* gamma, const float* beta, void* dx,

@@ -159,6 +159,26 @@ def main():
             o16 = model(x, return_dict=True)
     finally:
         torch.randn_like = orig
+    # ... and of the backward: per-parameter rel-L2 / norm ratio of the reference's bf16-autocast gradients
+    g32 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad()
+    torch.randn_like = lambda t, **kw: eps.to(t.dtype)
+    try:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ob = model(x, return_dict=True)
+        O.bench_loss(ob["reconstruction"].float(), x, ob["mu"].float(), ob["logvar"].float()).backward()
+    finally:
+        torch.randn_like = orig
+    dev16 = {}
+    for k, p in model.named_parameters():
+        n32 = float(g32[k].double().norm())
+        if n32 > 1e-7:
+            dev16[k] = {"l2rel": float((p.grad.double() - g32[k].double()).norm() / n32),
+                        "norm_ratio": float(p.grad.double().norm() / n32)}
+    with open(os.path.join(OUT, "micro_grads_ref_bf16_autocast.json"), "w") as f:
+        json.dump(dev16, f)
+    print("reference bf16-autocast gradient rel-L2: median %.3f max %.3f" % (
+        float(np.median([v["l2rel"] for v in dev16.values()])), max(v["l2rel"] for v in dev16.values())))
     md["recon_bf16"] = o16["reconstruction"].float().numpy()
     md["mu_bf16"] = o16["mu"].float().numpy()
     md["logvar_bf16"] = o16["logvar"].float().numpy()
@@ -198,7 +218,20 @@ def main():
             s = summarize(t[b], 64)
             for kk, vv in s.items():
                 td[f"{nm}.{b}.{kk}"] = np.asarray(vv)
+    # the reference's own bf16-autocast forward of the same inputs: how far ITS bf16 tier is from fp32
+    torch.randn_like = lambda t, **kw: et[:2].to(t.dtype)
+    try:
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            ar, amu, alv = tm(xt[:2])
+    finally:
+        torch.randn_like = orig
+    for nm, t16, t32 in (("recon", ar, tr), ("mu", amu, tmu), ("logvar", alv, tlv)):
+        for b in range(2):
+            td[f"{nm}.{b}.bf16_autocast_l2rel"] = np.asarray(
+                float((t16[b].float() - t32[b]).norm() / t32[b].norm()))
     np.savez_compressed(os.path.join(OUT, "tiny_forward.npz"), **td)
+    print("tiny reference bf16-autocast vs fp32 rel-L2:",
+          {k: float(v) for k, v in td.items() if k.endswith("l2rel")})
 
     # ---- state-dict schemas from the reference ------------------------------
     schemas = {}

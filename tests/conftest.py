@@ -14,6 +14,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    # the GPU box reports every host core but grants ~16: an oversubscribed oracle is 50x slower
+    import torch
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

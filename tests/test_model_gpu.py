@@ -1,0 +1,252 @@
+"""Module- and model-level parity of the HIP path (`-m gpu`).
+
+Two references, same seeded weights / inputs (oracle/filler.py):
+  * the committed golden vectors minted from the reference's own CPU path (tests/golden/*.npz)
+  * the fp32 CPU oracle, for shapes the goldens do not hold
+
+The HIP path stores activations in bf16 (fp32 accumulate).  Tolerances, all relative L2:
+  * single modules (one block deep): BASELINE's bf16 tier, 1e-2 on outputs; 3e-2 on gradients
+    (twice as many bf16 roundings on the way)
+  * whole models (30-100 ops deep): bf16 rounding accumulates; the yardstick is the reference's OWN
+    bf16 tier -- its bf16-autocast forward deviates from its fp32 forward by 2.0e-2 / 1.2e-2
+    (micro recon / mu) and 2.5-3.2e-2 / 1.3e-2 (tiny, BASELINE config 1), numbers stored in the
+    goldens.  We require  err <= max(1e-2, 1.25 * that deviation)  and measure 1.7e-2 / 1.0e-2
+    (micro) and 2.7e-2 / 1.2e-2 (tiny) -- see tools/precision_report.py.
+Runs are not bit-reproducible: GroupNorm statistics and weight gradients use fp32 atomics, whose
+summation order varies, and a flipped bf16 rounding propagates; equalities are therefore checked
+to tolerance.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import filler
+from oracle import transvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL_OUT, TOL_GRAD = 1e-2, 3e-2
+
+
+def l2rel(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().float().cpu() if torch.is_tensor(a) else a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b.detach().float().cpu() if torch.is_tensor(b) else b), dtype=torch.float64)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def golden(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def load_filled(mod, prefix):
+    mod.load_state_dict({k: filler.fill_tensor(prefix + k, v.shape) for k, v in mod.state_dict().items()})
+    return mod.to(DEV)
+
+
+def run_module(mod, prefix, xshape, g):
+    load_filled(mod, prefix)
+    x = filler.randn_input(prefix + "x", xshape).to(DEV).requires_grad_(True)
+    y = mod(x)
+    assert y.dtype == torch.float32 and tuple(y.shape) == tuple(g["y"].shape)
+    assert l2rel(y, g["y"]) < TOL_OUT, f"output {l2rel(y, g['y'])}"
+    y.backward(filler.randn_input(prefix + "gy", y.shape).to(DEV))
+    assert l2rel(x.grad, g["dx"]) < TOL_GRAD, f"dx {l2rel(x.grad, g['dx'])}"
+    for k, p in mod.named_parameters():
+        ref = g["d:" + k]
+        if np.abs(ref).max() < 1e-6:   # exactly-zero gradients (bias feeding a GroupNorm): only noise
+            assert float(p.grad.abs().max()) < 1e-2 * float(np.abs(g["dx"]).max()) + 1e-3, k
+            continue
+        assert l2rel(p.grad, ref) < TOL_GRAD, f"{k} {l2rel(p.grad, ref)}"
+
+
+def test_resblock(golden_dir):
+    from transvae.modules.blocks import ResBlock
+    run_module(ResBlock(64, 64), "resblock.", (2, 64, 16, 16), golden(golden_dir, "mod_resblock.npz"))
+
+
+def test_attention_128(golden_dir):
+    from transvae.modules.attention import FlashAttentionWithRoPE
+    run_module(FlashAttentionWithRoPE(128, 64), "attn128.", (2, 128, 8, 8), golden(golden_dir, "mod_attn128.npz"))
+
+
+def test_attention_64_nonsquare(golden_dir):
+    from transvae.modules.attention import FlashAttentionWithRoPE
+    run_module(FlashAttentionWithRoPE(64, 64), "attn64.", (1, 64, 16, 12), golden(golden_dir, "mod_attn64.npz"))
+
+
+def test_convffn(golden_dir):
+    from transvae.modules.conv import ConvFFN
+    run_module(ConvFFN(128), "convffn.", (2, 128, 8, 8), golden(golden_dir, "mod_convffn.npz"))
+
+
+def test_transvae_block(golden_dir):
+    from transvae.modules.blocks import TransVAEBlock
+    run_module(TransVAEBlock(dim=128), "tvblock.", (2, 128, 8, 8), golden(golden_dir, "mod_tvblock.npz"))
+
+
+def test_downsample(golden_dir):
+    from transvae.modules.upsample import Downsample
+    run_module(Downsample(64, 128), "down.", (2, 64, 16, 16), golden(golden_dir, "mod_down.npz"))
+
+
+def test_upsample(golden_dir):
+    from transvae.modules.upsample import Upsample
+    run_module(Upsample(128, 64), "up.", (2, 128, 8, 8), golden(golden_dir, "mod_up.npz"))
+
+
+def test_rmsnorm(golden_dir):
+    from transvae.modules.blocks import RMSNorm
+    g = golden(golden_dir, "mod_rmsnorm.npz")
+    m = load_filled(RMSNorm(128), "rmsnorm.")
+    x = filler.randn_input("rmsnorm.x", (2, 128, 8, 8)).to(DEV)
+    assert l2rel(m(x), g["y"]) < TOL_OUT
+
+
+@pytest.mark.parametrize("hw", [(4, 6), (16, 16)])
+def test_rope_module(golden_dir, hw):
+    from transvae.modules.attention import RoPE2D
+    H, W = hw
+    g = golden(golden_dir, "mod_rope.npz")
+    rope = RoPE2D(64).to(DEV)
+    t = filler.randn_input(f"rope.{H}x{W}", (1, 2, H * W, 64)).to(DEV)
+    assert l2rel(rope(t, H, W), g[f"y_{H}x{W}"]) < TOL_OUT
+
+
+def micro_model(**kw):
+    from transvae import TransVAE
+    m = TransVAE(config=dict(O.MICRO), variant="micro", compression_ratio=16, latent_dim=4, **kw)
+    m.load_state_dict(filler.fill_state_dict(O.state_dict_schema(O.MICRO, latent_dim=4)))
+    return m.to(DEV)
+
+
+def test_micro_model_against_reference_golden(golden_dir):
+    g = golden(golden_dir, "micro_model.npz")
+    m = micro_model()
+    x = filler.rand_input("micro.x", (2, 3, 64, 64)).to(DEV)
+    eps = filler.randn_input("micro.eps", (2, 4, 4, 4)).to(DEV)
+    z_in = filler.randn_input("micro.z", (2, 4, 4, 4)).to(DEV)
+    with torch.no_grad():
+        mu, logvar = m.encode(x)
+        assert mu.shape == (2, 4, 4, 4) and mu.dtype == torch.float32
+        tol = {k: max(1e-2, 1.25 * l2rel(g[k + "_bf16"], g[k])) for k in ("recon", "mu", "logvar")}
+        assert l2rel(mu, g["mu"]) < tol["mu"] and l2rel(logvar, g["logvar"]) < tol["logvar"]
+        assert l2rel(m.decode(z_in), g["dec_z"]) < tol["recon"]
+        assert l2rel(m.decoder(z_in), g["decoder_direct"]) < tol["recon"]   # P/generate_images.py:100-105 call style
+    out = m(x, return_dict=True, eps=eps)
+    assert set(out) == {"reconstruction", "mu", "logvar", "z"}
+    recon, mu, logvar = out["reconstruction"], out["mu"], out["logvar"]
+    assert recon.shape == x.shape
+    assert l2rel(recon, g["recon"]) < tol["recon"], l2rel(recon, g["recon"])
+    loss = O.bench_loss(recon, x, mu, logvar)
+    assert abs(float(loss) - float(g["loss"])) < 1e-2 * float(g["loss"])
+    loss.backward()
+    with open(os.path.join(golden_dir, "micro_grads.json")) as f:
+        gs = json.load(f)
+    params = dict(m.named_parameters())
+    # Gradients: the yardstick is again the reference's own bf16 tier.  Its bf16-autocast backward
+    # deviates from its fp32 backward by 5-24 % rel-L2 on the deep (encoder-side) parameters of this
+    # network and by <1 % on the last layer (micro_grads_ref_bf16_autocast.json); rounding noise is
+    # amplified by every block the gradient crosses.  We require at most 0.75x that deviation
+    # (floor 3e-2) on the full tensors we hold, and per-tensor norms within 15 % (median within 3 %).
+    with open(os.path.join(golden_dir, "micro_grads_ref_bf16_autocast.json")) as f:
+        ref16 = json.load(f)
+    devs = []
+    for k, s in gs.items():
+        if s["l2"] < 1e-7:
+            continue
+        got = float(params[k].grad.double().norm())
+        devs.append((abs(got - s["l2"]) / s["l2"], k))
+    assert max(devs)[0] < 0.15, max(devs)
+    assert float(np.median([d for d, _ in devs])) < 3e-2
+    for k in g:
+        if k.startswith("g:"):
+            err = l2rel(params[k[2:]].grad, g[k])
+            assert err < max(3e-2, 0.75 * ref16[k[2:]]["l2rel"]), (k, err, ref16[k[2:]]["l2rel"])
+
+
+def test_micro_model_tuple_forward_uses_global_rng_and_clamp_variant():
+    m = micro_model()
+    x = filler.rand_input("micro.x", (2, 3, 64, 64)).to(DEV)
+    torch.manual_seed(1)
+    r1, mu1, lv1 = m(x)
+    torch.manual_seed(1)
+    r2, _, _ = m(x)
+    assert l2rel(r1, r2) < 1e-2 and r1.shape == x.shape and mu1.shape == lv1.shape == (2, 4, 4, 4)
+    torch.manual_seed(2)
+    assert l2rel(m(x)[0], r1) > 2e-2          # a different eps draw changes the reconstruction
+    mc = micro_model(clamp_latent=True)          # patched copy's clamps are inactive on these weights
+    eps = filler.randn_input("micro.eps", (2, 4, 4, 4)).to(DEV)
+    assert l2rel(mc(x, eps=eps)[0], m(x, eps=eps)[0]) < 1e-2
+
+
+@pytest.mark.parametrize("res", [32, 64, 96])
+def test_resolutions_keep_shape(res):
+    """R/test_installation.py:90-113 (there 128/256/512 on the real variants)."""
+    m = micro_model()
+    x = torch.rand(1, 3, res, res, device=DEV)
+    with torch.no_grad():
+        recon, mu, logvar = m(x)
+    assert recon.shape == x.shape and mu.shape == (1, 4, res // 16, res // 16)
+    assert torch.isfinite(recon).all()
+
+
+def test_non_divisible_input_raises():
+    m = micro_model()
+    with pytest.raises(RuntimeError, match="divisible"):
+        m(torch.rand(1, 3, 40, 40, device=DEV))
+
+
+def test_gradient_checkpointing_backward_matches():
+    """R/test_installation.py:116-141: checkpointing + backward runs; here also: same gradients."""
+    x = filler.rand_input("micro.x", (2, 3, 64, 64)).to(DEV)
+    eps = filler.randn_input("micro.eps", (2, 4, 4, 4)).to(DEV)
+    grads = []
+    for ckpt in (False, True):
+        m = micro_model()
+        if ckpt:
+            m.enable_gradient_checkpointing()
+        m.train()
+        recon, mu, logvar = m(x, eps=eps)
+        torch.nn.functional.mse_loss(recon, x).backward()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        if float(a.abs().max()) > 1e-6:
+            assert l2rel(b, a) < TOL_GRAD, k
+
+
+def test_frozen_encoder_gets_no_gradients():
+    """R/train_2.py:441-444 freezes encoder parameters."""
+    m = micro_model()
+    for p in m.encoder.parameters():
+        p.requires_grad_(False)
+    x = filler.rand_input("micro.x", (2, 3, 64, 64)).to(DEV)
+    recon, mu, logvar = m(x)
+    recon.mean().backward()
+    assert all(p.grad is None for p in m.encoder.parameters())
+    assert m.decoder.conv_out.weight.grad is not None and m.conv_mu.weight.grad is not None
+
+
+def test_tiny_config1_against_reference_golden(golden_dir):
+    """BASELINE config 1 shapes (tiny f16d32, 256x256) on the GPU against the reference golden (image 0)."""
+    from transvae import TransVAE
+    g = golden(golden_dir, "tiny_forward.npz")
+    m = TransVAE(variant="tiny", compression_ratio=16, latent_dim=32)
+    m.load_state_dict(filler.fill_state_dict(O.state_dict_schema(O.variant_config("tiny", 16, 32), 32)))
+    m = m.to(DEV)
+    x = filler.rand_input("tiny.x", (4, 3, 256, 256))[:2].to(DEV)
+    eps = filler.randn_input("tiny.eps", (4, 32, 16, 16))[:2].to(DEV)
+    with torch.no_grad():
+        recon, mu, logvar = m(x, eps=eps)
+    for b in range(2):
+        for nm, t in (("recon", recon), ("mu", mu), ("logvar", logvar)):
+            flat = t[b].flatten().double().cpu().numpy()
+            ref = g[f"{nm}.{b}.val"]
+            got = flat[g[f"{nm}.{b}.idx"]]
+            err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+            # 64 sampled elements per tensor: a noisy estimate of the full-tensor error, hence 2x (not 1.25x)
+            assert err < max(1e-2, 2.0 * float(g[f"{nm}.{b}.bf16_autocast_l2rel"])), (nm, b, err)
+            assert abs(flat.std(ddof=1) - float(g[f"{nm}.{b}.std"])) < 2e-2 * float(g[f"{nm}.{b}.std"])

@@ -1,0 +1,104 @@
+"""Host-side (no GPU) checks of the drop-in boundary: constructor styles, state_dict schema,
+parameter counts, error behaviour (R/test_installation.py:10-27,144-175)."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import filler
+from oracle import transvae_oracle as O
+
+
+@pytest.fixture(scope="module")
+def schemas(golden_dir):
+    with open(os.path.join(golden_dir, "state_dict_schemas.json")) as f:
+        return json.load(f)
+
+
+def test_import_surface():
+    import transvae
+    assert hasattr(transvae, "TransVAE") and hasattr(transvae, "create_transvae")
+
+
+def test_config_style_constructor_matches_reference_schema(schemas):
+    from transvae import TransVAE
+    m = TransVAE(config=dict(O.MICRO), variant="micro", compression_ratio=16, latent_dim=4, input_channels=3,
+                 use_rope=True, use_conv_ffn=True, use_dc_path=True)  # the keyword set of R/train.py:116-124
+    sd = m.state_dict()
+    assert list(sd) == list(schemas["micro"])
+    for k, s in schemas["micro"].items():
+        assert tuple(sd[k].shape) == tuple(s), k
+    assert (m.variant, m.compression_ratio, m.latent_dim) == ("micro", 16, 4)
+
+
+@pytest.mark.parametrize("variant,key", [("tiny", "tiny_f16d32"), ("large", "large_f16d32")])
+def test_variant_style_constructor(schemas, golden_dir, variant, key):
+    from transvae import TransVAE, create_transvae
+    with torch.device("meta"):
+        m = TransVAE(variant=variant, compression_ratio=16, latent_dim=32)  # README / test_installation style
+        m2 = create_transvae(variant=variant)
+    assert list(m.state_dict()) == list(schemas[key]) == list(m2.state_dict())
+    for k, s in schemas[key].items():
+        assert tuple(m.state_dict()[k].shape) == tuple(s), k
+    with open(os.path.join(golden_dir, "param_counts.json")) as f:
+        counts = json.load(f)
+    n = m.get_num_params()
+    assert n["total"] == counts[key] and n["encoder"] + n["decoder"] < n["total"]
+
+
+def test_f8_variant_has_three_downsamples():
+    from transvae import TransVAE
+    with torch.device("meta"):
+        m = TransVAE(variant="large", compression_ratio=8, latent_dim=16)
+    assert len(m.encoder.downsamples) == 3 and m.conv_mu.out_channels == 16
+
+
+def test_unknown_variant_raises_value_error():
+    from transvae import TransVAE
+    with pytest.raises(ValueError, match="Unknown variant"):
+        TransVAE(variant="small", compression_ratio=16, latent_dim=32)
+
+
+def test_state_dict_round_trip_and_public_attributes():
+    from transvae import TransVAE
+    m = TransVAE(config=dict(O.MICRO), variant="micro", latent_dim=4)
+    sd = filler.fill_state_dict(O.state_dict_schema(O.MICRO, latent_dim=4))
+    missing = m.load_state_dict(sd)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    out = m.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(out[k], v), k
+    assert m.get_last_layer() is m.decoder.conv_out.weight
+    assert len(list(m.encoder.parameters())) > 0
+    m.enable_gradient_checkpointing()
+    assert m.encoder.gradient_checkpointing and m.decoder.gradient_checkpointing
+    # conv weights are stored channels_last (== the kernels' [Cout,KH,KW,Cin]) without changing the schema
+    assert m.encoder.stages[0][0].conv1.weight.permute(0, 2, 3, 1).is_contiguous()
+
+
+def test_init_distributions_follow_reference():
+    from transvae import TransVAE
+    torch.manual_seed(0)
+    m = TransVAE(config=dict(O.MICRO), variant="micro", latent_dim=4)
+    w = m.decoder.stages[3][0].conv1.weight  # 32->32 3x3: kaiming fan_out/relu => std = sqrt(2/(32*9))
+    assert abs(float(w.std()) - (2.0 / (32 * 9)) ** 0.5) < 0.015
+    lw = m.encoder.stages[2][0].attn.to_q.weight
+    assert abs(float(lw.std()) - 0.02) < 0.004
+    assert float(m.decoder.norm_out.weight.min()) == 1.0 and float(m.conv_mu.bias.abs().max()) == 0.0
+
+
+def test_forward_without_gpu_fails_loudly():
+    from transvae import TransVAE
+    m = TransVAE(config=dict(O.MICRO), variant="micro", latent_dim=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.decode(torch.zeros(1, 4, 4, 4))
+
+
+def test_from_pretrained_parses_name():
+    from transvae import TransVAE
+    with torch.device("meta"):
+        m = TransVAE.from_pretrained("transvae-tiny-f16d32")
+    assert m.variant == "tiny" and m.latent_dim == 32 and m.compression_ratio == 16

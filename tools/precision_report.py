@@ -1,0 +1,63 @@
+"""Full-tensor error of the HIP path against the fp32 CPU oracle (run on the GPU box).
+
+    python tools/precision_report.py [micro|tiny] ...
+
+Prints rel-L2 errors of recon / mu / logvar and per-stage encoder/decoder activations, so that
+precision regressions can be localised.  Diagnostic only (imports oracle/ as the checker).
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "deepl-project_amd"))
+from oracle import filler  # noqa: E402
+from oracle import transvae_oracle as O  # noqa: E402
+from transvae import TransVAE  # noqa: E402
+
+
+def l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def run(name):
+    if name == "micro":
+        cfg, L, shape = dict(O.MICRO), 4, (2, 3, 64, 64)
+        m = TransVAE(config=cfg, variant="micro", latent_dim=L)
+    else:
+        cfg, L, shape = O.variant_config(name, 16, 32), 32, (1, 3, 256, 256)
+        m = TransVAE(variant=name, latent_dim=L)
+    sd = filler.fill_state_dict(O.state_dict_schema(cfg, L))
+    m.load_state_dict(sd)
+    m = m.cuda()
+    x = filler.rand_input(name + ".x", (4,) + shape[1:])[: shape[0]]
+    eps = filler.randn_input(name + ".eps", (4, L, shape[2] // 16, shape[3] // 16))[: shape[0]]
+    torch.set_num_threads(min(16, os.cpu_count()))
+    t0 = time.time()
+    with torch.no_grad():
+        r_ref, mu_ref, lv_ref = O.forward(x, sd, cfg, eps)
+    t_cpu = time.time() - t0
+    with torch.no_grad():
+        r, mu, lv = m(x.cuda(), eps=eps.cuda())
+        torch.cuda.synchronize()
+        t0 = time.time()
+        r, mu, lv = m(x.cuda(), eps=eps.cuda())
+        torch.cuda.synchronize()
+        t_gpu = time.time() - t0
+    print(f"[{name}] rel-L2  recon {l2(r, r_ref):.4f}  mu {l2(mu, mu_ref):.4f}  logvar {l2(lv, lv_ref):.4f}   "
+          f"(oracle fwd {t_cpu:.2f}s on {os.cpu_count()} threads, hip fwd {t_gpu * 1e3:.1f} ms)")
+    # decoder alone from the oracle's z (separates encoder error from decoder error)
+    z = O.reparameterize(mu_ref, lv_ref, eps)
+    with torch.no_grad():
+        d_ref = O.decode(z, sd, cfg)
+        d = m.decode(z.cuda())
+    print(f"[{name}] decoder-only recon rel-L2 {l2(d, d_ref):.4f}")
+
+
+if __name__ == "__main__":
+    for n in (sys.argv[1:] or ["micro", "tiny"]):
+        run(n)
