@@ -84,6 +84,11 @@ __device__ __forceinline__ float tv_act(float z) {
     if constexpr (ACT == TV_ACT_SILU) return tv_silu(z);
     return z;
 }
+__device__ __forceinline__ float tv_act_rt(int act, float z) {
+    if (act == TV_ACT_GELU) return tv_gelu(z);
+    if (act == TV_ACT_SILU) return tv_silu(z);
+    return z;
+}
 __device__ __forceinline__ float tv_act_grad_rt(int act, float z) {
     if (act == TV_ACT_GELU) return tv_gelu_grad(z);
     if (act == TV_ACT_SILU) return tv_silu_grad(z);

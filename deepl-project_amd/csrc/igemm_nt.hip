@@ -9,12 +9,14 @@
 // gradient of a stride-2 conv), so one kernel serves nn.Linear, every Conv2d of the path
 // and their data gradients.
 //
-// Structure (cdna_hip_programming.md section 5, "minimum 2-phase"): 128-row tiles, 4 waves,
-// bf16 v_mfma_f32_16x16x32, operands staged global->LDS with 16-byte LDS-DMA
-// (global_load_lds_dwordx4) into two buffers: the loads of K-step t+1 are in flight while
-// K-step t is multiplied; one barrier per K-step.  The LDS image is lane-linear (DMA
-// constraint), bank conflicts are removed by XOR-swizzling the 16-byte chunk index on the
-// SOURCE address and on the ds_read_b128 address (rule 21).
+// Structure: 128- or 256-row tiles, 4 or 8 waves, bf16 v_mfma_f32_16x16x32, operands staged
+// global->LDS with 16-byte LDS-DMA (global_load_lds_dwordx4) into a ring of STAGES buffers.
+// The loads of K-steps t+1 .. t+STAGES-1 are in flight while K-step t is multiplied: one raw
+// s_barrier per K-step and a COUNTED s_waitcnt vmcnt(N) (never 0 in steady state when STAGES > 2),
+// so the DMA spans barriers (cdna_hip_programming.md section 5, "Pipelining across barriers",
+// T3/T4).  The LDS image is lane-linear (DMA constraint); bank conflicts are removed by
+// XOR-swizzling the 16-byte chunk index on the SOURCE address and on the ds_read_b128 address
+// (rule 21).
 //
 // The MFMA is issued as D' = W_frag x A_frag^T so that every lane ends up with 4*NF
 // consecutive output channels of one pixel: bias / activation / residual / store work on
@@ -37,7 +39,13 @@ struct IgemmArgs {
     int kh, kw, stride, pad, up_shift, dil_mask;
     int tiles_n;
     int shuffle;
+    int act;
 };
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 template <int BK>
 __device__ __forceinline__ int swz_of(int i) {  // i: row index inside a 16-row fragment
@@ -47,7 +55,7 @@ __device__ __forceinline__ int swz_of(int i) {  // i: row index inside a 16-row 
         return (0x78 >> (2 * ((i >> 2) & 3))) & 3;
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int ACT, bool DMA>
+template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, bool DMA>
 __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs p) {
     constexpr int NW = WGM * WGN;
     constexpr int CPR = BK / 8;     // 16-byte chunks per tile row
@@ -58,6 +66,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of 16");
     static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must fill whole DMA pieces");
+    static_assert(STAGES == 2 || (DMA && A_INSTR % NW == 0 && B_INSTR % NW == 0), "deep rings need uniform DMA counts per wave");
+    constexpr int NI = A_IT + B_IT;  // DMA instructions per thread and K-step
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -222,12 +232,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
 
     // ---- main loop -------------------------------------------------------------------------
     if constexpr (DMA) {
-        stage_issue(smem);
+        constexpr int LA = STAGES - 1;  // K-steps of lookahead
+#pragma unroll
+        for (int s = 0; s < LA; ++s)
+            if (s < nk) stage_issue(smem + s * STAGE);
+        int cur = 0, nxt = LA % STAGES;
         for (int t = 0; t < nk; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t + 1 < nk) stage_issue(smem + ((t + 1) & 1) * STAGE);
-            compute(smem + (t & 1) * STAGE);
+            // K-step t must have landed; up to min(LA-1, nk-1-t) younger K-steps may stay in flight
+            const int younger = min(LA - 1, nk - 1 - t);
+            if (LA >= 3 && younger == 2) wait_vmcnt<2 * NI>();
+            else if (LA >= 2 && younger == 1) wait_vmcnt<NI>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (t + LA < nk) stage_issue(smem + nxt * STAGE);
+            compute(smem + cur * STAGE);
+            cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+            nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
         }
     } else {
         stage_issue(smem);
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
                 *(bf16x4*)(p.pre + off) = pv;
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = tv_act<ACT>(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = tv_act_rt(p.act, v[e]);
             if (p.res) {
                 const bf16x4 rv = *(const bf16x4*)(p.res + off);
 #pragma unroll
@@ -291,58 +311,84 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
 }
 
 bool g_use_dma = true;
+int g_cfg_bm = 0;      // 0 = heuristic, else 128 / 256
+int g_cfg_stages = 0;  // 0 = heuristic, else 2 / 3 / 4
+int g_cfg_bk = 0;      // 0 = largest that divides c_in, else 32 / 64
+int g_cfg_bn = 0;      // 256 = use 256-wide N tiles when c_out % 256 == 0
 
-template <int BM, int BN, int WGM, int WGN, int BK, int ACT>
-int launch_cfg(const IgemmArgs& a, hipStream_t s) {
-    constexpr int STAGE = (BM + BN) * BK * 2;
-    const int tiles_m = (a.M + BM - 1) / BM;
-    dim3 grid((unsigned)(tiles_m * a.tiles_n)), block(WGM * WGN * 64);
-    static bool attr_done = false;
-    if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, ACT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, ACT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-        attr_done = true;
+constexpr int LDS_MAX = 160 * 1024;
+
+template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, bool DMA>
+int launch_one(const IgemmArgs& a, hipStream_t s) {
+    constexpr int BYTES = STAGES * (BM + BN) * BK * 2;
+    constexpr int RPI = 64 / (BK / 8), NW = WGM * WGN;
+    constexpr bool uniform = ((BM / RPI) % NW == 0) && ((BN / RPI) % NW == 0);  // same DMA count in every wave
+    if constexpr (BYTES > LDS_MAX || (STAGES > 2 && !uniform)) {
+        return -1;
+    } else {
+        const int tiles_m = (a.M + BM - 1) / BM;
+        dim3 grid((unsigned)(tiles_m * a.tiles_n)), block(WGM * WGN * 64);
+        static bool attr_done = false;
+        if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in
+            (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, DMA>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, DMA>), grid, block, BYTES, s, a);
+        return 0;
     }
-    if (g_use_dma)
-        hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, ACT, true>), grid, block, 2 * STAGE, s, a);
-    else
-        hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, ACT, false>), grid, block, 2 * STAGE, s, a);
-    return 0;
 }
 
-template <int BK, int ACT>
-int launch_bk(IgemmArgs& a, hipStream_t s) {
-    const int N = a.N;
-    if (N % 192 == 0 && N % 128 != 0) {
-        a.tiles_n = N / 192;
-        return launch_cfg<128, 192, 2, 2, BK, ACT>(a, s);
+// big-N tiles: BN in {128, 192, 256}; BM 128 (4 waves) or 256 (8 waves); ring depth 2..4
+template <int BN, int BK>
+int launch_big(const IgemmArgs& a, int bm, int stages, hipStream_t s) {
+    constexpr int WGM8 = (BN == 256) ? 2 : 4, WGN8 = (BN == 256) ? 4 : 2;  // 8-wave grids: wave tile 128x64 / 64x64 / 64x96
+    if (!g_use_dma) return launch_one<128, BN, 2, 2, BK, 2, false>(a, s);
+    if (bm == 256) {
+        if (stages == 4 && launch_one<256, BN, WGM8, WGN8, BK, 4, true>(a, s) == 0) return 0;
+        if (stages >= 3 && launch_one<256, BN, WGM8, WGN8, BK, 3, true>(a, s) == 0) return 0;
+        return launch_one<256, BN, WGM8, WGN8, BK, 2, true>(a, s);
     }
-    if (N > 64) {
-        a.tiles_n = (N + 127) / 128;
-        return launch_cfg<128, 128, 2, 2, BK, ACT>(a, s);
-    }
-    if (N > 32) {
-        a.tiles_n = 1;
-        return launch_cfg<128, 64, 2, 2, BK, ACT>(a, s);
-    }
-    a.tiles_n = 1;
-    return launch_cfg<128, 32, 4, 1, BK, ACT>(a, s);
+    if (stages == 4 && launch_one<128, BN, 2, 2, BK, 4, true>(a, s) == 0) return 0;
+    if (stages >= 3 && launch_one<128, BN, 2, 2, BK, 3, true>(a, s) == 0) return 0;
+    return launch_one<128, BN, 2, 2, BK, 2, true>(a, s);
 }
 
 template <int BK>
-int launch_act(IgemmArgs& a, int act, hipStream_t s) {
-    switch (act) {
-        case TV_ACT_NONE: return launch_bk<BK, TV_ACT_NONE>(a, s);
-        case TV_ACT_GELU: return launch_bk<BK, TV_ACT_GELU>(a, s);
-        case TV_ACT_SILU: return launch_bk<BK, TV_ACT_SILU>(a, s);
+int launch_bk(IgemmArgs& a, hipStream_t s) {
+    const int N = a.N;
+    const int bm = g_cfg_bm ? g_cfg_bm : 128;
+    const int stages = g_cfg_stages ? g_cfg_stages : 2;
+    if (N % 192 == 0 && N % 128 != 0) {
+        a.tiles_n = N / 192;
+        return launch_big<192, BK>(a, bm, stages, s);
     }
-    return -1;
+    if (g_cfg_bn == 256 && N % 256 == 0) {
+        a.tiles_n = N / 256;
+        return launch_big<256, BK>(a, bm, stages, s);
+    }
+    if (N > 64) {
+        a.tiles_n = (N + 127) / 128;
+        return launch_big<128, BK>(a, bm, stages, s);
+    }
+    a.tiles_n = 1;
+    if (N > 32) return g_use_dma ? launch_one<128, 64, 2, 2, BK, 2, true>(a, s) : launch_one<128, 64, 2, 2, BK, 2, false>(a, s);
+    return g_use_dma ? launch_one<128, 32, 4, 1, BK, 2, true>(a, s) : launch_one<128, 32, 4, 1, BK, 2, false>(a, s);
 }
 
 }  // namespace
 
 extern "C" int tv_set_dma(int on) {
     g_use_dma = on != 0;
+    return 0;
+}
+
+// tuning hook (tools/gemm_sweep.py): 0 restores the built-in heuristic
+extern "C" int tv_set_igemm_config(int bm, int bn, int stages, int bk) {
+    g_cfg_bm = bm;
+    g_cfg_bn = bn;
+    g_cfg_stages = stages;
+    g_cfg_bk = bk;
     return 0;
 }
 
@@ -383,8 +429,10 @@ extern "C" int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, 
     a.up_shift = d->up_shift; a.dil_mask = d->dil_mask;
     a.tiles_n = 1;
     a.shuffle = d->store_shuffle;
+    a.act = d->act;
     hipStream_t s = (hipStream_t)stream;
-    int rc = (d->c_in % 64 == 0) ? launch_act<64>(a, d->act, s) : launch_act<32>(a, d->act, s);
+    const bool bk64 = (d->c_in % 64 == 0) && g_cfg_bk != 32;
+    int rc = bk64 ? launch_bk<64>(a, s) : launch_bk<32>(a, s);
     if (rc != 0) {
         tv_set_error("tv_igemm_nt: no kernel for this configuration");
         return TV_ERR_ARG;

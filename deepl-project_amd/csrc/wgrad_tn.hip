@@ -28,7 +28,7 @@ struct WgradArgs {
     int batch, h_in, w_in, c_in, ldx;
     int h_out, w_out, c_out, ldo;
     int kh, kw, stride, pad, up_shift, dil_mask;
-    int tiles_ci, chunk_px;
+    int tiles_ci, chunk_px, hw_shift, w_shift;
 };
 
 // physical 16-byte slot of logical chunk c in pixel-row r of a [32][TW] tile
@@ -43,25 +43,55 @@ __device__ __forceinline__ int tn_swz(int c, int r) {
     }
 }
 
-__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `younger` K-steps (NI DMA instructions each) are still in flight
+template <int NI, int K>
+struct WaitSel {
+    static __device__ __forceinline__ void run(int younger) {
+        if (younger == K) wait_vmcnt<K * NI>();
+        else WaitSel<NI, K - 1>::run(younger);
+    }
+};
+template <int NI>
+struct WaitSel<NI, 0> {
+    static __device__ __forceinline__ void run(int) { wait_vmcnt<0>(); }
+};
+
+// ds_read_b64_tr_b16 through inline asm: with the builtin, hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in
+// front of every transposed read while an LDS-DMA is in flight (it does not for plain ds_read_b128), which
+// drains the ring each K-step.  An asm read is invisible to that pass; its completion is waited for by the
+// explicit lgkmcnt(0) + sched_barrier pairs below (cdna_hip_programming.md section 5.7, rule 18).
+__device__ __forceinline__ bf16x4 lds_tr16(unsigned lds_addr) {
+    bf16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_wait_all() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int TG, int TX>
-__global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradArgs p) {
-    constexpr int NW = 4;
+template <int TG, int TX, int STAGES, int NWN>
+__global__ __launch_bounds__(128 * NWN) void wgrad_tn_kernel(const WgradArgs p) {
+    constexpr int NW = 2 * NWN;                           // waves: 2 over co x NWN over ci
     constexpr int CG = TG / 8, CX = TX / 8;               // chunks per tile row
     constexpr int G_INSTR = TG / 16, X_INSTR = TX / 16;   // 1 KiB pieces per 32-pixel tile
-    constexpr int G_IT = G_INSTR / NW, X_IT = X_INSTR / NW;
+    constexpr int G_IT = (G_INSTR + NW - 1) / NW, X_IT = (X_INSTR + NW - 1) / NW;
     constexpr int G_BYTES = 32 * TG * 2, X_BYTES = 32 * TX * 2, STAGE = G_BYTES + X_BYTES;
-    constexpr int WTG = TG / 2, WTX = TX / 2, MF = WTG / 16, NF = WTX / 16;
-    static_assert(G_INSTR % NW == 0 && X_INSTR % NW == 0, "tile widths must be multiples of 64");
+    constexpr int WTG = TG / 2, WTX = TX / NWN, MF = WTG / 16, NF = WTX / 16;
+    static_assert(WTX % 16 == 0, "wave tile must be a multiple of 16");
+    static_assert(STAGES == 2 || (G_INSTR % NW == 0 && X_INSTR % NW == 0), "deep rings need uniform DMA counts per wave");
+    constexpr int NI = G_IT + X_IT;  // DMA instructions per thread and K-step
+    static_assert((STAGES - 2) * NI <= 63, "vmcnt is a 6-bit counter");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
 
     const int taps = p.kh * p.kw;
     int bx = blockIdx.x;
@@ -108,6 +138,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradArgs p) {
         const int pz = p_begin + step * 32;
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
+            if (G_INSTR % NW != 0 && it * NW + wave >= G_INSTR) break;
             const int px = pz + g_row[it];
             const bool ok = g_cok[it] && px < p_end;
             const void* src = ok ? (const void*)(p.gy + (size_t)px * p.ldo + g_col[it])
@@ -116,12 +147,21 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradArgs p) {
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
+            if (X_INSTR % NW != 0 && it * NW + wave >= X_INSTR) break;
             const int px = pz + x_row[it];
             bool ok = x_cok[it] && px < p_end;
-            const int b = px / hw;
-            const int r = px - b * hw;
-            const int oy = r / p.w_out;
-            const int ox = r - oy * p.w_out;
+            int b, oy, ox;
+            if (p.w_shift >= 0) {  // power-of-two grid (every real TransVAE stage): shifts, no division
+                b = px >> p.hw_shift;
+                const int r = px & (hw - 1);
+                oy = r >> p.w_shift;
+                ox = r & (p.w_out - 1);
+            } else {
+                b = px / hw;
+                const int r = px - b * hw;
+                oy = r / p.w_out;
+                ox = r - oy * p.w_out;
+            }
             const int uy = oy * p.stride + ky - p.pad, ux = ox * p.stride + kx - p.pad;
             ok = ok && ((unsigned)uy < (unsigned)hv) && ((unsigned)ux < (unsigned)wv) &&
                  (((uy | ux) & p.dil_mask) == 0);
@@ -163,38 +203,63 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradArgs p) {
     const bf16 one = (bf16)1.0f;
     const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
-    auto compute = [&](const char* sbase) {
-        bf16x8 af[MF], bfr[NF];
+    const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto join = [](bf16x4 lo, bf16x4 hi) { return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
+    auto compute = [&](int stage) {
+        const unsigned sb = smem_addr + stage * STAGE;
+        constexpr int H = (NF + 1) / 2;
+        bf16x4 alo[MF], ahi[MF], blo[NF], bhi[NF];
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
-            const bf16x4 lo = lds_tr16(sbase + a_off[0][i]);
-            const bf16x4 hi = lds_tr16(sbase + a_off[1][i]);
-            af[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            alo[i] = lds_tr16(sb + a_off[0][i]);
+            ahi[i] = lds_tr16(sb + a_off[1][i]);
         }
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const bf16x4 lo = lds_tr16(sbase + b_off[0][j]);
-            const bf16x4 hi = lds_tr16(sbase + b_off[1][j]);
-            bfr[j] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        for (int j = 0; j < H; ++j) {
+            blo[j] = lds_tr16(sb + b_off[0][j]);
+            bhi[j] = lds_tr16(sb + b_off[1][j]);
         }
+        lds_wait_all();
+#pragma unroll
+        for (int j = H; j < NF; ++j) {  // second batch lands while the first half multiplies
+            blo[j] = lds_tr16(sb + b_off[0][j]);
+            bhi[j] = lds_tr16(sb + b_off[1][j]);
+        }
+        bf16x8 af[MF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) af[i] = join(alo[i], ahi[i]);
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
-            for (int j = 0; j < NF; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < H; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], join(blo[j], bhi[j]), acc[i][j], 0, 0, 0);
         if (do_bias) {
 #pragma unroll
             for (int i = 0; i < MF; ++i)
                 accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
         }
+        lds_wait_all();
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = H; j < NF; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], join(blo[j], bhi[j]), acc[i][j], 0, 0, 0);
     };
 
-    stage_issue(0, smem);
+    // ring of STAGES buffers: K-steps t+1 .. t+STAGES-1 stay in flight across the (raw) barriers while
+    // step t is multiplied -- the kernel is otherwise bound by memory latency, not by MFMA or bytes
+    constexpr int LA = STAGES - 1;
+#pragma unroll
+    for (int s = 0; s < LA; ++s)
+        if (s < nsteps) stage_issue(s, smem + s * STAGE);
+    int cur = 0, nxt = LA % STAGES;
     for (int t = 0; t < nsteps; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nsteps) stage_issue(t + 1, smem + ((t + 1) & 1) * STAGE);
-        compute(smem + (t & 1) * STAGE);
+        WaitSel<NI, LA - 1>::run(min(LA - 1, nsteps - 1 - t));
+        __builtin_amdgcn_s_barrier();
+        if (t + LA < nsteps) stage_issue(t + LA, smem + nxt * STAGE);
+        compute(cur);
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+        nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
     }
 
     // ---- fp32 atomics into dw[co][tap][ci]; D layout: row = (lane>>4)*4+reg (co), col = lane&15 (ci)
@@ -216,10 +281,29 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradArgs p) {
     }
 }
 
+int g_wgrad_stages = 0;  // 0 = heuristic
+int g_wgrad_waves = 0;   // 0 = heuristic (8 waves for the 192-wide co tile), 4 / 8 = force
+
+template <int TG, int TX, int STAGES, int NWN>
+int launch_s(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int BYTES = STAGES * 32 * (TG + TX) * 2;
+    constexpr bool uniform = ((TG / 16) % (2 * NWN) == 0) && ((TX / 16) % (2 * NWN) == 0);
+    if constexpr (BYTES > 160 * 1024 || (STAGES > 2 && !uniform) || (TX / NWN) % 16 != 0) {
+        return -1;
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<TG, TX, STAGES, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((wgrad_tn_kernel<TG, TX, STAGES, NWN>), grid, dim3(128 * NWN), BYTES, s, a);
+        return 0;
+    }
+}
+
 template <int TG, int TX>
 int launch(const WgradArgs& a0, hipStream_t s) {
     WgradArgs a = a0;
-    constexpr int STAGE = 32 * (TG + TX) * 2;
     const int tiles_co = (a.c_out + TG - 1) / TG;
     a.tiles_ci = (a.c_in + TX - 1) / TX;
     const long long base = (long long)tiles_co * a.tiles_ci * a.kh * a.kw;
@@ -229,17 +313,25 @@ int launch(const WgradArgs& a0, hipStream_t s) {
     chunk = (chunk + 31) / 32 * 32;
     a.chunk_px = (int)chunk;
     const int ny = (int)((a.M + chunk - 1) / chunk);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<TG, TX>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
-        attr_done = true;
-    }
-    dim3 grid((unsigned)base, (unsigned)ny), block(256);
-    hipLaunchKernelGGL((wgrad_tn_kernel<TG, TX>), grid, block, 2 * STAGE, s, a);
-    return 0;
+    dim3 grid((unsigned)base, (unsigned)ny);
+    auto log2_exact = [](int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; };
+    a.w_shift = log2_exact(a.w_out);
+    a.hw_shift = log2_exact(a.h_out * a.w_out);
+    if (a.hw_shift < 0) a.w_shift = -1;
+    const int st = g_wgrad_stages ? g_wgrad_stages : 2;
+    // 8 waves (2 per SIMD) for the wide tiles: one wave's transposed-read phase overlaps the other's MFMAs
+    if (g_wgrad_waves != 4 && (TG == 192 || g_wgrad_waves == 8) && TX >= 128 && launch_s<TG, TX, 2, 4>(a, grid, s) == 0) return 0;
+    if (st >= 4 && launch_s<TG, TX, 4, 2>(a, grid, s) == 0) return 0;
+    return launch_s<TG, TX, 2, 2>(a, grid, s);
 }
 
 }  // namespace
+
+extern "C" int tv_set_wgrad_config(int stages, int waves) {
+    g_wgrad_stages = stages;
+    g_wgrad_waves = waves;
+    return 0;
+}
 
 extern "C" int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias,
                            void* stream) {
@@ -266,7 +358,7 @@ extern "C" int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy,
     a.h_out = d->h_out; a.w_out = d->w_out; a.c_out = d->c_out; a.ldo = d->ldo;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
     a.up_shift = d->up_shift; a.dil_mask = d->dil_mask;
-    a.tiles_ci = 1; a.chunk_px = 0;
+    a.tiles_ci = 1; a.chunk_px = 0; a.hw_shift = -1; a.w_shift = -1;
     hipStream_t s = (hipStream_t)stream;
     const bool g192 = (d->c_out % 192 == 0) && (d->c_out % 128 != 0);
     const bool x192 = (d->c_in % 192 == 0) && (d->c_in % 128 != 0);
