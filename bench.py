@@ -78,10 +78,16 @@ def time_dominant_kernel(mb: int, res: int, dev):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     flop = 2.0 * mb * res * res * C * 9 * C
+    traffic = None   # HBM bytes per launch from the committed rocprofv3 --pmc passes (scaled by image count)
+    pmc = os.path.join(ROOT, "profiles", "r01_dominant_kernel_pmc.json")
+    if os.path.exists(pmc) and res == 256:
+        with open(pmc) as f:
+            j = json.load(f)
+        traffic = round(j["hbm_bytes_per_launch"] * mb / j["images"])
     return {"bound": "mfma", "kernel": "igemm_nt_kernel<128,192,2,2,64> (conv3x3 192->192 @%dx%d, %d images)" % (res, res, mb),
             "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
-            "traffic": None}
+            "traffic": traffic}
 
 
 def cpu_baseline(variant: str, res: int, threads: int):
@@ -131,7 +137,12 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--kernel-only", action="store_true", help="only time the dominant kernel (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
+    if args.kernel_only:
+        torch.cuda.set_device(0)
+        print(json.dumps(time_dominant_kernel(args.micro_batch, args.res, torch.device("cuda", 0))), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
