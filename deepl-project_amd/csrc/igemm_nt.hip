@@ -40,7 +40,19 @@ struct IgemmArgs {
     int tiles_n;
     int shuffle;
     int act;
+    unsigned x_bytes, w_bytes;  // MODE 2: extents of the two buffers (< 2 GiB)
 };
+
+constexpr int OOB_OFFSET = (int)0x80000000u;  // beyond any < 2 GiB buffer: the LDS-DMA writes zeros
+
+// 16-byte LDS-DMA through a buffer descriptor: lds[base + lane*16] = buf[voff + soff .. +16) or zeros if out of range.
+// The descriptor type only exists in the device pass (a kernel body naming it loses its host stub), hence the guard.
+__device__ __forceinline__ void buffer_load_lds16(const void* base, unsigned bytes, char* lds, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000),
+                                             TV_LDS(lds), 16, voff, soff, 0, 0);
+#endif
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -55,8 +67,13 @@ __device__ __forceinline__ int swz_of(int i) {  // i: row index inside a 16-row 
         return (0x78 >> (2 * ((i >> 2) & 3))) & 3;
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, bool DMA>
+// MODE 0: register-staged loads + ds_write (bring-up / debugging)
+// MODE 1: global_load_lds with 64-bit per-lane addresses (tensors >= 2 GiB)
+// MODE 2: buffer_load ... lds: SGPR descriptor + 32-bit per-lane offset fixed per tap + scalar K offset; padding
+//         = out-of-range offset (the hardware writes zeros) -- no vector ALU work per DMA in the steady state
+template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE>
 __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs p) {
+    constexpr bool DMA = MODE != 0, BUF = MODE == 2;
     constexpr int NW = WGM * WGN;
     constexpr int CPR = BK / 8;     // 16-byte chunks per tile row
     constexpr int RPI = 64 / CPR;   // tile rows covered by one wave-wide 1 KiB piece
@@ -66,7 +83,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of 16");
     static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must fill whole DMA pieces");
-    static_assert(STAGES == 2 || (DMA && A_INSTR % NW == 0 && B_INSTR % NW == 0), "deep rings need uniform DMA counts per wave");
+    static_assert(STAGES == 2 || DMA, "deep rings are DMA only");
+    // deep rings count DMA instructions per wave (vmcnt): waves that own no piece in the last round issue a
+    // dummy 1 KiB DMA from the zero page into a scratch slot behind the ring, so every wave issues NI per K-step
+    constexpr bool PADDED = STAGES > 2 && (A_INSTR % NW != 0 || B_INSTR % NW != 0);
     constexpr int NI = A_IT + B_IT;  // DMA instructions per thread and K-step
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,6 +126,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
     }
     const bf16* b_src[B_IT];
     bool b_ok[B_IT];
+    int b_voff[B_IT];
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int j = it * NW + wave;
@@ -116,6 +137,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
         const int n = n0 + row;
         b_ok[it] = (j < B_INSTR) && (n < p.N);
         b_src[it] = p.w + (size_t)(b_ok[it] ? n : 0) * p.K + c;
+        b_voff[it] = b_ok[it] ? (n * p.K + c) * 2 : OOB_OFFSET;
     }
 
     // running state of the "next K-step to stage"
@@ -124,6 +146,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
     int st_ky = 0, st_kx = 0, st_ch = 0, st_t = 0;
     const bf16* a_src[A_IT];
     bool a_ok[A_IT];
+    int a_voff[A_IT];
     const int hv = p.h_in << p.up_shift, wv = p.w_in << p.up_shift;
 
     auto tap_setup = [&]() {
@@ -135,7 +158,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
             const int iy = uy >> p.up_shift, ix = ux >> p.up_shift;
             const int pix = a_pix[it] + iy * p.w_in + ix;
             a_ok[it] = ok;
-            a_src[it] = p.x + (size_t)(ok ? pix : 0) * p.ldx + a_chunk[it];
+            if constexpr (BUF) a_voff[it] = ok ? (pix * p.ldx + a_chunk[it]) * 2 : OOB_OFFSET;
+            else a_src[it] = p.x + (size_t)(ok ? pix : 0) * p.ldx + a_chunk[it];
         }
     };
     tap_setup();
@@ -148,8 +172,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int j = it * NW + wave;
-            if (A_INSTR % NW != 0 && j >= A_INSTR) break;
-            if constexpr (DMA) {
+            if (A_INSTR % NW != 0 && j >= A_INSTR) {
+                if constexpr (PADDED && BUF) buffer_load_lds16(p.x, p.x_bytes, smem + STAGES * STAGE, OOB_OFFSET, 0);
+                else if constexpr (PADDED) __builtin_amdgcn_global_load_lds(TV_GLB(p.zeros + lane * 16), TV_LDS(smem + STAGES * STAGE), 16, 0, 0);
+                break;
+            }
+            if constexpr (BUF) {
+                buffer_load_lds16(p.x, p.x_bytes, sbase + j * 1024, a_voff[it], koff * 2);
+            } else if constexpr (DMA) {
                 const void* src = a_ok[it] ? (const void*)(a_src[it] + koff) : (const void*)(p.zeros + lane * 16);
                 __builtin_amdgcn_global_load_lds(TV_GLB(src), TV_LDS(sbase + j * 1024), 16, 0, 0);
             } else {
@@ -162,8 +192,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int j = it * NW + wave;
-            if (B_INSTR % NW != 0 && j >= B_INSTR) break;
-            if constexpr (DMA) {
+            if (B_INSTR % NW != 0 && j >= B_INSTR) {
+                if constexpr (PADDED && BUF) buffer_load_lds16(p.w, p.w_bytes, smem + STAGES * STAGE, OOB_OFFSET, 0);
+                else if constexpr (PADDED) __builtin_amdgcn_global_load_lds(TV_GLB(p.zeros + lane * 16), TV_LDS(smem + STAGES * STAGE), 16, 0, 0);
+                break;
+            }
+            if constexpr (BUF) {
+                buffer_load_lds16(p.w, p.w_bytes, sbase + A_BYTES + j * 1024, b_voff[it], kb * 2);
+            } else if constexpr (DMA) {
                 const void* src = b_ok[it] ? (const void*)(b_src[it] + kb) : (const void*)(p.zeros + lane * 16);
                 __builtin_amdgcn_global_load_lds(TV_GLB(src), TV_LDS(sbase + A_BYTES + j * 1024), 16, 0, 0);
             } else {
@@ -315,71 +351,79 @@ int g_cfg_bm = 0;      // 0 = heuristic, else 128 / 256
 int g_cfg_stages = 0;  // 0 = heuristic, else 2 / 3 / 4
 int g_cfg_bk = 0;      // 0 = largest that divides c_in, else 32 / 64
 int g_cfg_bn = 0;      // 256 = use 256-wide N tiles when c_out % 256 == 0
+int g_addr_mode = 0;   // 0 = buffer DMA when the tensors are < 2 GiB, 1 = force 64-bit global DMA
 
 constexpr int LDS_MAX = 160 * 1024;
 
-template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, bool DMA>
+template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE>
 int launch_one(const IgemmArgs& a, hipStream_t s) {
-    constexpr int BYTES = STAGES * (BM + BN) * BK * 2;
-    constexpr int RPI = 64 / (BK / 8), NW = WGM * WGN;
-    constexpr bool uniform = ((BM / RPI) % NW == 0) && ((BN / RPI) % NW == 0);  // same DMA count in every wave
-    if constexpr (BYTES > LDS_MAX || (STAGES > 2 && !uniform)) {
+    constexpr int BYTES = STAGES * (BM + BN) * BK * 2 + (STAGES > 2 ? 1024 : 0);  // + dummy-DMA scratch slot
+    if constexpr (BYTES > LDS_MAX) {
         return -1;
     } else {
         const int tiles_m = (a.M + BM - 1) / BM;
         dim3 grid((unsigned)(tiles_m * a.tiles_n)), block(WGM * WGN * 64);
         static bool attr_done = false;
         if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in
-            (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, DMA>,
+            (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
             attr_done = true;
         }
-        hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, DMA>), grid, block, BYTES, s, a);
+        hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE>), grid, block, BYTES, s, a);
         return 0;
     }
 }
 
-// big-N tiles: BN in {128, 192, 256}; BM 128 (4 waves) or 256 (8 waves); ring depth 2..4
-template <int BN, int BK>
+// big-N tiles: BN in {128, 192, 256}; BM 128 (4 waves) or 256 (8 waves); ring depth 2..3
+template <int BN, int BK, int MODE>
 int launch_big(const IgemmArgs& a, int bm, int stages, hipStream_t s) {
     constexpr int WGM8 = (BN == 256) ? 2 : 4, WGN8 = (BN == 256) ? 4 : 2;  // 8-wave grids: wave tile 128x64 / 64x64 / 64x96
-    if (!g_use_dma) return launch_one<128, BN, 2, 2, BK, 2, false>(a, s);
-    if (bm == 256) {
-        if (stages == 4 && launch_one<256, BN, WGM8, WGN8, BK, 4, true>(a, s) == 0) return 0;
-        if (stages >= 3 && launch_one<256, BN, WGM8, WGN8, BK, 3, true>(a, s) == 0) return 0;
-        return launch_one<256, BN, WGM8, WGN8, BK, 2, true>(a, s);
+    if constexpr (MODE == 0) {
+        return launch_one<128, BN, 2, 2, BK, 2, 0>(a, s);
+    } else {
+        if (bm == 256) {
+            if (stages >= 3 && launch_one<256, BN, WGM8, WGN8, BK, 3, MODE>(a, s) == 0) return 0;
+            return launch_one<256, BN, WGM8, WGN8, BK, 2, MODE>(a, s);
+        }
+        if (stages >= 3 && launch_one<128, BN, 2, 2, BK, 3, MODE>(a, s) == 0) return 0;
+        return launch_one<128, BN, 2, 2, BK, 2, MODE>(a, s);
     }
-    if (stages == 4 && launch_one<128, BN, 2, 2, BK, 4, true>(a, s) == 0) return 0;
-    if (stages >= 3 && launch_one<128, BN, 2, 2, BK, 3, true>(a, s) == 0) return 0;
-    return launch_one<128, BN, 2, 2, BK, 2, true>(a, s);
 }
 
-template <int BK>
-int launch_bk(IgemmArgs& a, hipStream_t s) {
+template <int BK, int MODE>
+int launch_mode(IgemmArgs& a, hipStream_t s) {
     const int N = a.N;
     const int bm = g_cfg_bm ? g_cfg_bm : 128;
     const int stages = g_cfg_stages ? g_cfg_stages : 2;
     if (N % 192 == 0 && N % 128 != 0) {
         a.tiles_n = N / 192;
-        return launch_big<192, BK>(a, bm, stages, s);
+        return launch_big<192, BK, MODE>(a, bm, stages, s);
     }
     if (g_cfg_bn == 256 && N % 256 == 0) {
         a.tiles_n = N / 256;
-        return launch_big<256, BK>(a, bm, stages, s);
+        return launch_big<256, BK, MODE>(a, bm, stages, s);
     }
     if (N > 64) {
         a.tiles_n = (N + 127) / 128;
-        return launch_big<128, BK>(a, bm, stages, s);
+        return launch_big<128, BK, MODE>(a, bm, stages, s);
     }
     a.tiles_n = 1;
-    if (N > 32) return g_use_dma ? launch_one<128, 64, 2, 2, BK, 2, true>(a, s) : launch_one<128, 64, 2, 2, BK, 2, false>(a, s);
-    return g_use_dma ? launch_one<128, 32, 4, 1, BK, 2, true>(a, s) : launch_one<128, 32, 4, 1, BK, 2, false>(a, s);
+    if (N > 32) return launch_one<128, 64, 2, 2, BK, 2, MODE>(a, s);
+    return launch_one<128, 32, 4, 1, BK, 2, MODE>(a, s);
+}
+
+template <int BK>
+int launch_bk(IgemmArgs& a, hipStream_t s) {
+    if (!g_use_dma) return launch_mode<BK, 0>(a, s);
+    if (g_addr_mode != 1 && a.x_bytes != 0 && a.w_bytes != 0) return launch_mode<BK, 2>(a, s);
+    return launch_mode<BK, 1>(a, s);
 }
 
 }  // namespace
 
-extern "C" int tv_set_dma(int on) {
+extern "C" int tv_set_dma(int on) {   // 0: register staging, 1: LDS-DMA (buffer form when possible), 2: LDS-DMA, global form only
     g_use_dma = on != 0;
+    g_addr_mode = (on == 2) ? 1 : 0;
     return 0;
 }
 
@@ -430,6 +474,12 @@ extern "C" int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, 
     a.tiles_n = 1;
     a.shuffle = d->store_shuffle;
     a.act = d->act;
+    {   // buffer-descriptor extents (0 = too large for 32-bit offsets -> global-address DMA)
+        const long long xb = ((long long)d->batch * d->h_in * d->w_in - 1) * d->ldx * 2 + (long long)d->c_in * 2;
+        const long long wb = (long long)a.N * a.K * 2;
+        a.x_bytes = xb < (1ll << 31) ? (unsigned)xb : 0u;
+        a.w_bytes = wb < (1ll << 31) ? (unsigned)wb : 0u;
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool bk64 = (d->c_in % 64 == 0) && g_cfg_bk != 32;
     int rc = bk64 ? launch_bk<64>(a, s) : launch_bk<32>(a, s);
