@@ -72,7 +72,7 @@ typedef struct tv_conv_desc {
  * Replaces F.conv2d / nn.Linear at R/transvae/modules/blocks.py:34,37, conv.py:39,54-60,65,
  * attention.py:43-48, upsample.py:33-37,42,93-98,103, the conv_in / conv_out / conv_mu / conv_logvar of models/{encoder,decoder,transvae}.py,
  * and -- called with rotated/transposed weights -- their data gradients.
- * Requires c_in % 32 == 0, c_out % 4 == 0, ldx % 8 == 0, ldo % 4 == 0.
+ * Requires c_in % 32 == 0, c_out % 8 == 0, ldx % 8 == 0, ldo % 8 == 0 (bias, residual, pre_act, out 16-byte aligned).
  */
 int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, const float* bias,
                 const void* residual, void* pre_act, void* out, void* stream);
