@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--variant", default="large")
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--global-batch", type=int, default=256)
-    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--micro-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--kernel-only", action="store_true", help="only time the dominant kernel (for rocprofv3 --pmc passes)")

@@ -81,15 +81,16 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--cfg", default="", help="igemm tuning: bm,bn,stages,bk (0 = heuristic)")
     ap.add_argument("--brief", action="store_true")
-    ap.add_argument("--wstages", type=int, default=0, help="wgrad ring depth (0 = heuristic)")
+    ap.add_argument("--wstages", type=int, default=0, help="wgrad pixels per K-step (0 = heuristic, 32, 64)")
+    ap.add_argument("--wblocks", type=int, default=0, help="wgrad split-K block target (0 = heuristic)")
     ap.add_argument("--wwaves", type=int, default=0, help="wgrad waves per block (0 = heuristic, 4)")
     args = ap.parse_args()
     if args.cfg:
         from transvae.hip import _lib
         _lib.load().tv_set_igemm_config(*[int(v) for v in args.cfg.split(",")])
-    if args.wstages or args.wwaves:
+    if args.wstages or args.wwaves or args.wblocks:
         from transvae.hip import _lib
-        _lib.load().tv_set_wgrad_config(args.wstages, args.wwaves)
+        _lib.load().tv_set_wgrad_config(args.wstages, args.wwaves, args.wblocks)
     dev = torch.device("cuda:0")
     rows = []
     for (name, mode, B, H, W, Cin, Cout), count in layer_list(args.variant, args.res, args.mb).items():
@@ -133,7 +134,7 @@ def main():
         tf = sum(c * a for _, _, c, _, a, b, d in rows)
         tb = sum(c * b for _, _, c, _, a, b, d in rows)
         tw = sum(c * d for _, _, c, _, a, b, d in rows)
-        print(f"cfg={args.cfg or 'default':12s} wst={args.wstages} ww={args.wwaves} fwd {tf:7.1f} ms  dgrad {tb:7.1f} ms  wgrad {tw:7.1f} ms  total {tot:7.1f} ms")
+        print(f"cfg={args.cfg or 'default':12s} wbkp={args.wstages} ww={args.wwaves} wblk={args.wblocks} fwd {tf:7.1f} ms  dgrad {tb:7.1f} ms  wgrad {tw:7.1f} ms  total {tot:7.1f} ms")
         for name, mode, c, f, a, b, d in rows:
             if name in ("res192@256", "ffn_c3x31536@16", "ffn_in1536@16", "ffn_in384@64", "proj1536@16", "qkv768@32", "ffn_out768@32"):
                 print(f"    {name:20s} fwd {f / a / 1e9:5.0f} TF/s   dgrad {f / b / 1e9:5.0f} TF/s   wgrad {f / d / 1e9:5.0f} TF/s")
