@@ -30,6 +30,7 @@ struct IgemmArgs {
     const bf16* w;
     const float* bias;
     const bf16* res;
+    const bf16* aux;   // backward fusion: out = (acc + res) * act'(aux)
     bf16* pre;
     bf16* out;
     const char* zeros;
@@ -40,6 +41,7 @@ struct IgemmArgs {
     int tiles_n;
     int shuffle;
     int act;
+    int aux_act;
     int hw_shift, w_shift;  // log2 of h_out*w_out / w_out when both are powers of two, else -1
     unsigned x_bytes, w_bytes;  // MODE 2: extents of the two buffers (< 2 GiB)
 };
@@ -353,7 +355,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
         }
         bf16x8 z = *(const bf16x8*)(ebuf + r * ERS + c8 * 16);
         if (p.pre) *(bf16x8*)(p.pre + off) = z;
-        if (p.act != TV_ACT_NONE || p.res) {
+        if (p.aux) {  // gradient w.r.t. a pre-activation: (acc + residual gradient) * act'(saved pre-activation)
+            const bf16x8 av = *(const bf16x8*)(p.aux + off);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)z[e];
+            if (p.res) {
+                const bf16x8 rv = *(const bf16x8*)(p.res + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (bf16)(v[e] * tv_act_grad_rt(p.aux_act, (float)av[e]));
+        } else if (p.act != TV_ACT_NONE || p.res) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = tv_act_rt(p.act, (float)z[e]);
@@ -461,8 +475,23 @@ extern "C" int tv_set_igemm_config(int bm, int bn, int stages, int bk) {
     return 0;
 }
 
+static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                         void* pre_act, void* out, const void* aux, int aux_act, void* stream);
+
 extern "C" int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, const float* bias,
                            const void* residual, void* pre_act, void* out, void* stream) {
+    return igemm_nt_impl(d, x, w, bias, residual, pre_act, out, nullptr, TV_ACT_NONE, stream);
+}
+
+extern "C" int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const void* w, const void* residual,
+                                   const void* aux_pre_act, int aux_act, void* out, void* stream) {
+    TV_CHECK_ARG(aux_pre_act && aux_act >= 0 && aux_act <= 2 && d && d->act == TV_ACT_NONE,
+                 "tv_igemm_nt_actgrad: needs the saved pre-activation, a valid activation id and desc.act == NONE");
+    return igemm_nt_impl(d, x, w, nullptr, residual, nullptr, out, aux_pre_act, aux_act, stream);
+}
+
+static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
+                         void* pre_act, void* out, const void* aux, int aux_act, void* stream) {
     TV_CHECK_ARG(d && x && w && out, "tv_igemm_nt: null pointer");
     TV_CHECK_ARG(d->c_in > 0 && d->c_in % 32 == 0, "tv_igemm_nt: c_in=%d must be a multiple of 32", d->c_in);
     TV_CHECK_ARG(d->c_out > 0 && d->c_out % 8 == 0, "tv_igemm_nt: c_out=%d must be a multiple of 8", d->c_out);
@@ -486,6 +515,8 @@ extern "C" int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, 
     a.w = (const bf16*)w;
     a.bias = bias;
     a.res = (const bf16*)residual;
+    a.aux = (const bf16*)aux;
+    a.aux_act = aux_act;
     a.pre = (bf16*)pre_act;
     a.out = (bf16*)out;
     a.zeros = (const char*)tv_zero_page();

@@ -1,0 +1,267 @@
+"""Block-level autograd Functions: one forward / one hand-orchestrated backward per TransVAE block.
+
+Per-op autograd (ops.ConvFn etc.) is correct but leaves three kinds of avoidable HBM passes in the
+backward, all visible in the rocprof summary (profiles/): a separate GELU/SiLU-backward pass per
+activation, autograd's add kernels wherever a tensor has two consumers (every residual), and zero
+fills.  Here each block's backward is written out explicitly, so that
+
+  * activation backward rides in the epilogue of the data-gradient GEMM that produces the incoming
+    gradient (`tv_igemm_nt_actgrad`: out = (acc + residual) * act'(pre)),
+  * the second gradient of a residual stream is added inside GroupNorm-backward / row-norm-backward
+    (`dres`) or a GEMM epilogue (`residual`),
+  * nothing is materialised twice.
+
+Math and parameter layouts are those of ops.py; reference lines are cited there and in modules/*.py.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import BF16, _p, _stream, conv_dgrad, conv_forward, conv_wgrad
+
+GELU, SILU, NONE = L.ACT_GELU, L.ACT_SILU, L.ACT_NONE
+
+
+# ------------------------------------------------------------------------------------------------
+# raw GroupNorm / row-norm / attention calls
+# ------------------------------------------------------------------------------------------------
+def gn_silu_fwd(x, gamma, beta, groups, eps):
+    B, H, W, Cc = x.shape
+    lib = L.load()
+    stats = torch.empty((B, Cc, 2), dtype=torch.float32, device=x.device)
+    part = torch.empty((lib.tv_gn_partial_count(B, H * W, Cc),), dtype=torch.float32, device=x.device)
+    L.check(lib.tv_gn_stats(_p(x), _p(stats), _p(part), B, H * W, Cc, _stream()), "tv_gn_stats")
+    mr = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    L.check(lib.tv_gn_silu_fwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(mr), _p(y), B, H * W, Cc, groups, eps, _stream()),
+            "tv_gn_silu_fwd")
+    return y, mr
+
+
+def gn_silu_bwd(x, dy, dres, mr, gamma, beta, groups):
+    """(dx [+ dres], dgamma, dbeta)"""
+    B, H, W, Cc = x.shape
+    lib = L.load()
+    red = torch.empty((B, Cc, 2), dtype=torch.float32, device=x.device)
+    part = torch.empty((lib.tv_gn_partial_count(B, H * W, Cc),), dtype=torch.float32, device=x.device)
+    L.check(lib.tv_gn_silu_bwd_reduce(_p(x), _p(dy), _p(mr), _p(gamma), _p(beta), _p(red), _p(part), B, H * W, Cc, groups,
+                                      _stream()), "tv_gn_silu_bwd_reduce")
+    dx = torch.empty_like(x)
+    dg = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
+    db = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
+    L.check(lib.tv_gn_silu_bwd_apply(_p(x), _p(dy), _p(dres), _p(mr), _p(red), _p(gamma), _p(beta), _p(dx), _p(dg), _p(db),
+                                     B, H * W, Cc, groups, _stream()), "tv_gn_silu_bwd_apply")
+    return dx, dg, db
+
+
+def rownorm_fwd(x, w, mode, eps_rms, eps_ln):
+    T, Cc = x.shape
+    y = torch.empty_like(x)
+    L.check(L.load().tv_rownorm_fwd(_p(x), _p(w), _p(y), T, Cc, mode, eps_rms, eps_ln, _stream()), "tv_rownorm_fwd")
+    return y
+
+
+def rownorm_bwd(x, w, dy, dres, mode, eps_rms, eps_ln):
+    T, Cc = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.zeros((Cc,), dtype=torch.float32, device=x.device) if mode == 1 else None
+    L.check(L.load().tv_rownorm_bwd(_p(x), _p(w), _p(dy), _p(dres), _p(dx), _p(dw), T, Cc, mode, eps_rms, eps_ln, _stream()),
+            "tv_rownorm_bwd")
+    return dx, dw
+
+
+def _c(t):
+    return t.contiguous() if t is not None else None
+
+
+def _wg(ctx, iw, ib, geo, w, x, gz):
+    """weight / bias gradient of one layer, skipped when neither input of the Function needs it (frozen parameters)."""
+    need_w, need_b = ctx.needs_input_grad[iw], ctx.needs_input_grad[ib]
+    if not (need_w or need_b):
+        return None, None
+    dw, db = conv_wgrad(geo, w, x, gz, need_b)
+    return (dw if need_w else None), db
+
+
+# ------------------------------------------------------------------------------------------------
+# ResBlock (identity shortcut)   R/transvae/modules/blocks.py:48-68
+# ------------------------------------------------------------------------------------------------
+class ResBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g1, b1, w1, c1b, g2, b2, w2, c2b, eps1, eps2):
+        ops._need_gpu(x)
+        g1, b1, g2, b2 = _c(g1), _c(b1), _c(g2), _c(b2)
+        a1, mr1 = gn_silu_fwd(x, g1, b1, 32, eps1)
+        h1, _, geo1, w1c = conv_forward(a1, w1, c1b, None, "c3s1", NONE, False)
+        a2, mr2 = gn_silu_fwd(h1, g2, b2, 32, eps2)
+        out, _, geo2, w2c = conv_forward(a2, w2, c2b, x, "c3s1", NONE, False)
+        ctx.geo = (geo1, geo2)
+        ctx.save_for_backward(x, a1, h1, a2, mr1, mr2, g1, b1, g2, b2, w1c, w2c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a1, h1, a2, mr1, mr2, g1, b1, g2, b2, w1, w2 = ctx.saved_tensors
+        geo1, geo2 = ctx.geo
+        g = g.contiguous()
+        da2 = conv_dgrad(geo2, w2, g, a2.shape)
+        dw2, dc2b = _wg(ctx, 7, 8, geo2, w2, a2, g)
+        dh1, dg2, db2 = gn_silu_bwd(h1, da2, None, mr2, g2, b2, 32)
+        del da2
+        da1 = conv_dgrad(geo1, w1, dh1, a1.shape)
+        dw1, dc1b = _wg(ctx, 3, 4, geo1, w1, a1, dh1)
+        dx, dg1, db1 = gn_silu_bwd(x, da1, g, mr1, g1, b1, 32)    # + skip-connection gradient, fused
+        return dx, dg1, db1, dw1, dc1b, dg2, db2, dw2, dc2b, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# attention branch of a TransVAE block:  t + proj(attn(rope(qkv(LN-hat(RMSNorm(t))))))
+# ------------------------------------------------------------------------------------------------
+class AttnBranchFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, w_rms, wqkv, bqkv, wp, bp, tab, B, N, heads, scale, eps_rms, eps_ln):
+        ops._need_gpu(t)
+        lib = L.load()
+        w_rms = _c(w_rms)
+        Cc = t.shape[1]
+        xh = rownorm_fwd(t, w_rms, 1, eps_rms, eps_ln)
+        qkv, _, geo_q, wq = conv_forward(xh, wqkv, _c(bqkv), None, "linear", NONE, False)
+        if tab is not None:
+            L.check(lib.tv_rope_qk(_p(qkv), _p(tab), B, N, heads, 0, _stream()), "tv_rope_qk")
+        o = torch.empty((B * N, Cc), dtype=BF16, device=t.device)
+        lse = torch.empty((B, heads, N), dtype=torch.float32, device=t.device)
+        L.check(lib.tv_attn_fwd(_p(qkv), _p(o), _p(lse), B, N, heads, scale, _stream()), "tv_attn_fwd")
+        out, _, geo_p, wpc = conv_forward(o, wp, _c(bp), t, "linear", NONE, False)
+        ctx.geo = (geo_q, geo_p)
+        ctx.meta = (B, N, heads, scale, eps_rms, eps_ln)
+        ctx.save_for_backward(t, w_rms, xh, qkv, o, lse, wq, wpc, tab)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        t, w_rms, xh, qkv, o, lse, wq, wp, tab = ctx.saved_tensors
+        geo_q, geo_p = ctx.geo
+        B, N, heads, scale, eps_rms, eps_ln = ctx.meta
+        lib = L.load()
+        g = g.contiguous()
+        do = conv_dgrad(geo_p, wp, g, o.shape)
+        dwp, dbp = _wg(ctx, 4, 5, geo_p, wp, o, g)
+        delta = torch.empty((B, heads, N), dtype=torch.float32, device=t.device)
+        dqkv = torch.empty_like(qkv)
+        L.check(lib.tv_attn_bwd(_p(qkv), _p(o), _p(do), _p(lse), _p(delta), None, _p(dqkv), B, N, heads, scale, _stream()),
+                "tv_attn_bwd")
+        if tab is not None:
+            L.check(lib.tv_rope_qk(_p(dqkv), _p(tab), B, N, heads, 1, _stream()), "tv_rope_qk")
+        dxh = conv_dgrad(geo_q, wq, dqkv, xh.shape)
+        dwq, dbq = _wg(ctx, 2, 3, geo_q, wq, xh, dqkv)
+        dt, dw_rms = rownorm_bwd(t, w_rms, dxh, g, 1, eps_rms, eps_ln)     # + residual gradient, fused
+        return dt, dw_rms, dwq, dbq, dwp, dbp, None, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv-FFN branch:  t + W_out (u + W3 gelu(K3x3 gelu(W1 u))) ,  u = gelu(W_in RMS-hat(t))
+# ------------------------------------------------------------------------------------------------
+class ConvFFNBranchFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, w_in, b_in, w1, b1, w2, b2, w3, b3, w_out, b_out, B, H, W, eps_rms):
+        ops._need_gpu(t)
+        T, d = t.shape
+        train = any(ctx.needs_input_grad)
+        r = rownorm_fwd(t, None, 0, eps_rms, 1e-5)
+        u, pre_u, geo_in, w_in_c = conv_forward(r, w_in, _c(b_in), None, "linear", GELU, train)
+        c1, pre_c1, geo1, w1c = conv_forward(u, w1, _c(b1), None, "linear", GELU, train)
+        mid = c1.shape[1]
+        c2, pre_c2, geo2, w2c = conv_forward(c1.view(B, H, W, mid), w2, _c(b2), None, "c3s1", GELU, train)
+        u2, _, geo3, w3c = conv_forward(c2.view(T, mid), w3, _c(b3), u, "linear", NONE, False)
+        out, _, geo_out, w_out_c = conv_forward(u2, w_out, _c(b_out), t, "linear", NONE, False)
+        ctx.geo = (geo_in, geo1, geo2, geo3, geo_out)
+        ctx.meta = (B, H, W, eps_rms)
+        ctx.save_for_backward(t, r, u, pre_u, c1, pre_c1, c2, pre_c2, u2, w_in_c, w1c, w2c, w3c, w_out_c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        t, r, u, pre_u, c1, pre_c1, c2, pre_c2, u2, w_in, w1, w2, w3, w_out = ctx.saved_tensors
+        geo_in, geo1, geo2, geo3, geo_out = ctx.geo
+        B, H, W, eps_rms = ctx.meta
+        T, d = t.shape
+        mid = c1.shape[1]
+        g = g.contiguous()
+        du2 = conv_dgrad(geo_out, w_out, g, u2.shape)                                   # [T,4d]
+        dw_out, db_out = _wg(ctx, 9, 10, geo_out, w_out, u2, g)
+        gz_c2 = conv_dgrad(geo3, w3, du2, (T, mid), aux=pre_c2.view(T, mid), aux_act=GELU)   # d/d pre_c2
+        dw3, db3 = _wg(ctx, 7, 8, geo3, w3, c2.view(T, mid), du2)
+        gz_c2 = gz_c2.view(B, H, W, mid)
+        gz_c1 = conv_dgrad(geo2, w2, gz_c2, (B, H, W, mid), aux=pre_c1.view(B, H, W, mid), aux_act=GELU)
+        dw2, db2 = _wg(ctx, 5, 6, geo2, w2, c1.view(B, H, W, mid), gz_c2)
+        gz_c1 = gz_c1.view(T, mid)
+        gz_u = conv_dgrad(geo1, w1, gz_c1, u.shape, residual=du2, aux=pre_u, aux_act=GELU)   # (W1^T gz_c1 + du2) * gelu'(pre_u)
+        dw1, db1 = _wg(ctx, 3, 4, geo1, w1, u, gz_c1)
+        del du2
+        dr = conv_dgrad(geo_in, w_in, gz_u, r.shape)
+        dw_in, db_in = _wg(ctx, 1, 2, geo_in, w_in, r, gz_u)
+        dt, _ = rownorm_bwd(t, None, dr, g, 0, eps_rms, 1e-5)                           # + residual gradient, fused
+        return dt, dw_in, db_in, dw1, db1, dw2, db2, dw3, db3, dw_out, db_out, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# Downsample / Upsample with DC path   R/transvae/modules/upsample.py:44-66, 110-128
+# ------------------------------------------------------------------------------------------------
+class DownsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w0, b0, w2, b2, wdc, bdc):
+        ops._need_gpu(x)
+        dc, gdc, wdcc = None, None, None
+        if wdc is not None:
+            dc, _, gdc, wdcc = conv_forward(x, wdc, _c(bdc), None, "unshuf", NONE, False)
+        h, pre_h, g0, w0c = conv_forward(x, w0, _c(b0), None, "c3s1", SILU, any(ctx.needs_input_grad))
+        out, _, g2, w2c = conv_forward(h, w2, _c(b2), dc, "c3s2", NONE, False)
+        ctx.geo = (g0, g2, gdc)
+        ctx.save_for_backward(x, h, pre_h, w0c, w2c, wdcc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, h, pre_h, w0, w2, wdc = ctx.saved_tensors
+        g0, g2, gdc = ctx.geo
+        g = g.contiguous()
+        gz_h = conv_dgrad(g2, w2, g, h.shape, aux=pre_h, aux_act=SILU)
+        dw2, db2 = _wg(ctx, 3, 4, g2, w2, h, g)
+        dx = conv_dgrad(g0, w0, gz_h, x.shape)
+        dw0, db0 = _wg(ctx, 1, 2, g0, w0, x, gz_h)
+        dwdc = dbdc = None
+        if wdc is not None:
+            dx = conv_dgrad(gdc, wdc, g, x.shape, residual=dx)                          # DC-path gradient + main path, fused
+            dwdc, dbdc = _wg(ctx, 5, 6, gdc, wdc, x, g)
+        return dx, dw0, db0, dw2, db2, dwdc, dbdc
+
+
+class UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w3, b3, wdc, bdc):
+        ops._need_gpu(x)
+        dc, gdc, wdcc = None, None, None
+        if wdc is not None:
+            dc, _, gdc, wdcc = conv_forward(x, wdc, _c(bdc), None, "shuf", NONE, False)
+        h, pre_h, g1, w1c = conv_forward(x, w1, _c(b1), None, "c3up", SILU, any(ctx.needs_input_grad))
+        out, _, g3, w3c = conv_forward(h, w3, _c(b3), dc, "c3s1", NONE, False)
+        ctx.geo = (g1, g3, gdc)
+        ctx.save_for_backward(x, h, pre_h, w1c, w3c, wdcc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, h, pre_h, w1, w3, wdc = ctx.saved_tensors
+        g1, g3, gdc = ctx.geo
+        g = g.contiguous()
+        gz_h = conv_dgrad(g3, w3, g, h.shape, aux=pre_h, aux_act=SILU)
+        dw3, db3 = _wg(ctx, 3, 4, g3, w3, h, g)
+        dx = conv_dgrad(g1, w1, gz_h, x.shape)
+        dw1, db1 = _wg(ctx, 1, 2, g1, w1, x, gz_h)
+        dwdc = dbdc = None
+        if wdc is not None:
+            dx = conv_dgrad(gdc, wdc, g, x.shape, residual=dx)
+            dwdc, dbdc = _wg(ctx, 5, 6, gdc, wdc, x, g)
+        return dx, dw1, db1, dw3, db3, dwdc, dbdc

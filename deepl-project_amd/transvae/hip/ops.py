@@ -149,6 +149,114 @@ class _Geo:
         raise ValueError(m)
 
 
+# ---- the three passes of one layer as plain functions (shared by ConvFn and the fused block Functions) ----
+def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre: bool):
+    """Returns (out, pre_activation | None, geometry, contiguous fp32 weight)."""
+    _need_gpu(x, w)
+    assert x.dtype == BF16 and x.is_contiguous(), "activations must be contiguous bf16 NHWC"
+    assert w.dtype == torch.float32
+    w = w.contiguous()
+    g = _Geo(mode, x, w)
+    wb, _ = pack_weight(w.view(g.Cout, g.KH * g.KW, g.Cin), True, False, False)
+    out = torch.empty(g.out_shape, dtype=BF16, device=x.device)
+    pre = torch.empty_like(out) if (want_pre and act_id != L.ACT_NONE) else None
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == BF16 and residual.is_contiguous()
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == g.Cout
+    igemm(g.fwd_desc(act_id), x, wb, bias, residual, pre, out)
+    return out, pre, g, w
+
+
+def _igemm_bwd(desc, gz, wt, residual, aux, aux_act, dx):
+    """dx = conv(gz, wt) [+ residual] [* act'(aux)]"""
+    if aux is None:
+        igemm(desc, gz, wt, None, residual, None, dx)
+    else:
+        lib = L.load()
+        L.check(lib.tv_igemm_nt_actgrad(C.byref(desc), _p(gz), _p(wt), _p(residual), _p(aux), aux_act, _p(dx), _stream()),
+                "tv_igemm_nt_actgrad")
+
+
+def conv_dgrad(g: _Geo, w, gz, x_shape, residual=None, aux=None, aux_act: int = 0):
+    """Gradient w.r.t. the layer input.  Optional fusions (one kernel, no extra pass):
+    residual: a second gradient of the same tensor to add;  aux/aux_act: multiply by act'(aux), i.e. return the
+    gradient w.r.t. the pre-activation `aux` of the layer that produced this layer's input."""
+    lib = L.load()
+    m = g.mode
+    T = g.KH * g.KW
+    dev = gz.device
+    if m == "unshuf":  # GEMM rows n = (dy,dx,c): transpose the flattened [Cout, 4*Cin] matrix
+        _, wt = pack_weight(w.view(g.Cout, 1, T * g.Cin), False, True, False)
+    else:              # [Cin][taps (reversed for 3x3)][Cout]
+        _, wt = pack_weight(w.view(g.Cout, T, g.Cin), False, True, m in ("c3s1", "c3s2", "c3up"))
+    dx = torch.empty(x_shape, dtype=BF16, device=dev)
+    if m == "linear":
+        d = _desc(batch=g.B, h_in=1, w_in=1, c_in=g.Cout, ldx=g.Cout, h_out=1, w_out=1, c_out=g.Cin, ldo=g.Cin, kh=1, kw=1)
+        _igemm_bwd(d, gz, wt, residual, aux, aux_act, dx)
+    elif m == "c3s1":
+        d = _desc(batch=g.B, h_in=g.H, w_in=g.W, c_in=g.Cout, ldx=g.Cout, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
+                  kh=3, kw=3, stride=1, pad=1)
+        _igemm_bwd(d, gz, wt, residual, aux, aux_act, dx)
+    elif m == "c3s2":
+        d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
+                  kh=3, kw=3, stride=1, pad=1, up_shift=1, dil_mask=1)
+        _igemm_bwd(d, gz, wt, residual, aux, aux_act, dx)
+    elif m == "c3up":
+        du = torch.empty((g.B, g.Ho, g.Wo, g.Cin), dtype=BF16, device=dev)
+        d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.Ho, w_out=g.Wo, c_out=g.Cin, ldo=g.Cin,
+                  kh=3, kw=3, stride=1, pad=1)
+        igemm(d, gz, wt, None, None, None, du)
+        L.check(lib.tv_pool2x2_sum(_p(du), _p(dx), g.B, g.H, g.W, g.Cin, _stream()), "tv_pool2x2_sum")
+        if residual is not None:
+            L.check(lib.tv_add_(_p(dx), _p(residual), dx.numel(), _stream()), "tv_add_")
+        if aux is not None:
+            L.check(lib.tv_act_bwd(_p(aux), _p(dx), _p(dx), dx.numel(), aux_act, _stream()), "tv_act_bwd")
+    elif m == "unshuf":
+        # dx[b,2oy+dy,2ox+dx,c] = sum_co gz[b,oy,ox,co] W[co,dy,dx,c]  -> GEMM with shuffled store
+        d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.Ho, w_out=g.Wo, c_out=4 * g.Cin, ldo=g.Cin,
+                  kh=1, kw=1, store_shuffle=1)
+        _igemm_bwd(d, gz, wt, residual, aux, aux_act, dx)
+    elif m == "shuf":
+        # dx[p,ci] = sum_{q,c} gz_hi[pix(p,q),c] W[(q,c),ci]  -> 2x2/stride-2 gather conv over gz_hi
+        cq = g.Cout // 4
+        d = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
+                  kh=2, kw=2, stride=2, pad=0)
+        _igemm_bwd(d, gz, wt, residual, aux, aux_act, dx)
+    else:
+        raise ValueError(m)
+    return dx
+
+
+def conv_wgrad(g: _Geo, w, x, gz, need_db: bool):
+    """(dw in w's layout, dbias | None), fp32."""
+    dev = x.device
+    db = torch.zeros((g.Cout,), dtype=torch.float32, device=dev) if need_db else None
+    if g.mode != "shuf":
+        dw = torch.zeros_like(w, memory_format=torch.contiguous_format)
+        wgrad(g.fwd_desc(0), x, gz, dw, db)
+        return dw, db
+    cq = g.Cout // 4
+    d = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
+              kh=2, kw=2, stride=2, pad=0)
+    dwt = torch.zeros((g.Cin, 2, 2, cq), dtype=torch.float32, device=dev)
+    wgrad(d, gz, x, dwt, None)     # the transposed problem: gathered operand = hi-res gradient
+    dw = dwt.permute(1, 2, 3, 0).reshape(g.Cout, 1, 1, g.Cin).contiguous()
+    if need_db:
+        d1 = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=8, ldo=8,
+                   kh=2, kw=2, stride=2, pad=0)
+        tmp = torch.zeros((8, 2, 2, cq), dtype=torch.float32, device=dev)
+        wgrad(d1, gz, _ones(g.B * g.H * g.W, dev), tmp, None)
+        db = tmp[0].reshape(g.Cout).contiguous()
+    return dw, db
+
+
+def act_backward(pre, gy, act_id: int):
+    gz = torch.empty_like(gy)
+    L.check(L.load().tv_act_bwd(_p(pre), _p(gy), _p(gz), gy.numel(), act_id, _stream()), "tv_act_bwd")
+    return gz
+
+
 class ConvFn(torch.autograd.Function):
     """out = act(conv(x, w) + bias) + residual   on bf16 NHWC activations.
 
@@ -159,100 +267,26 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, residual, mode: str, act: Optional[str]):
-        _need_gpu(x, w)
-        assert x.dtype == BF16 and x.is_contiguous(), "activations must be contiguous bf16 NHWC"
-        assert w.dtype == torch.float32
-        w = w.contiguous()
-        g = _Geo(mode, x, w)
         act_id = _act_id(act)
-        wb, _ = pack_weight(w.view(g.Cout, g.KH * g.KW, g.Cin), True, False, False)
-        out = torch.empty(g.out_shape, dtype=BF16, device=x.device)
-        need_pre = act_id != L.ACT_NONE and (x.requires_grad or w.requires_grad)
-        pre = torch.empty_like(out) if need_pre else None
-        if residual is not None:
-            assert residual.shape == out.shape and residual.dtype == BF16 and residual.is_contiguous()
-        if bias is not None:
-            assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == g.Cout
-        igemm(g.fwd_desc(act_id), x, wb, bias, residual, pre, out)
+        out, pre, g, wc = conv_forward(x, w, bias, residual, mode, act_id, x.requires_grad or w.requires_grad)
         ctx.geo, ctx.act_id = g, act_id
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
-        ctx.save_for_backward(x, w, pre)
+        ctx.save_for_backward(x, wc, pre)
         return out
 
     @staticmethod
     def backward(ctx, gy):
         x, w, pre = ctx.saved_tensors
         g: _Geo = ctx.geo
-        lib = L.load()
         gy = gy.contiguous()
         assert gy.dtype == BF16
         gres = gy if ctx.has_res else None
-        if ctx.act_id != L.ACT_NONE:
-            gz = torch.empty_like(gy)
-            L.check(lib.tv_act_bwd(_p(pre), _p(gy), _p(gz), gy.numel(), ctx.act_id, _stream()), "tv_act_bwd")
-        else:
-            gz = gy
+        gz = act_backward(pre, gy, ctx.act_id) if ctx.act_id != L.ACT_NONE else gy
         need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        dx = dw = db = None
-        m = g.mode
-        T = g.KH * g.KW
-        if need_dx:
-            if m == "unshuf":  # GEMM rows n = (dy,dx,c): transpose the flattened [Cout, 4*Cin] matrix
-                _, wt = pack_weight(w.view(g.Cout, 1, T * g.Cin), False, True, False)
-            else:              # [Cin][taps (reversed for 3x3)][Cout]
-                _, wt = pack_weight(w.view(g.Cout, T, g.Cin), False, True, m in ("c3s1", "c3s2", "c3up"))
-            if m == "linear":
-                dx = torch.empty((g.B, g.Cin), dtype=BF16, device=x.device)
-                d = _desc(batch=g.B, h_in=1, w_in=1, c_in=g.Cout, ldx=g.Cout, h_out=1, w_out=1, c_out=g.Cin, ldo=g.Cin, kh=1, kw=1)
-                igemm(d, gz, wt, None, None, None, dx)
-            elif m == "c3s1":
-                dx = torch.empty_like(x)
-                d = _desc(batch=g.B, h_in=g.H, w_in=g.W, c_in=g.Cout, ldx=g.Cout, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
-                          kh=3, kw=3, stride=1, pad=1)
-                igemm(d, gz, wt, None, None, None, dx)
-            elif m == "c3s2":
-                dx = torch.empty_like(x)
-                d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
-                          kh=3, kw=3, stride=1, pad=1, up_shift=1, dil_mask=1)
-                igemm(d, gz, wt, None, None, None, dx)
-            elif m == "c3up":
-                du = torch.empty((g.B, g.Ho, g.Wo, g.Cin), dtype=BF16, device=x.device)
-                d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.Ho, w_out=g.Wo, c_out=g.Cin, ldo=g.Cin,
-                          kh=3, kw=3, stride=1, pad=1)
-                igemm(d, gz, wt, None, None, None, du)
-                dx = torch.empty_like(x)
-                L.check(lib.tv_pool2x2_sum(_p(du), _p(dx), g.B, g.H, g.W, g.Cin, _stream()), "tv_pool2x2_sum")
-            elif m == "unshuf":
-                # dx[b,2oy+dy,2ox+dx,c] = sum_co gz[b,oy,ox,co] W[co,dy,dx,c]  -> GEMM with shuffled store
-                dx = torch.empty_like(x)
-                d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.Ho, w_out=g.Wo, c_out=4 * g.Cin, ldo=g.Cin,
-                          kh=1, kw=1, store_shuffle=1)
-                igemm(d, gz, wt, None, None, None, dx)
-            elif m == "shuf":
-                # dx[p,ci] = sum_{q,c} gz_hi[pix(p,q),c] W[(q,c),ci]  -> 2x2/stride-2 gather conv over gz_hi
-                cq = g.Cout // 4
-                dx = torch.empty_like(x)
-                d = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
-                          kh=2, kw=2, stride=2, pad=0)
-                igemm(d, gz, wt, None, None, None, dx)
+        dx = conv_dgrad(g, w, gz, x.shape) if need_dx else None
+        dw = db = None
         if need_dw or need_db:
-            db = torch.zeros((g.Cout,), dtype=torch.float32, device=x.device) if need_db else None
-            if m != "shuf":
-                dw = torch.zeros_like(w, memory_format=torch.contiguous_format)
-                wgrad(g.fwd_desc(0), x, gz, dw, db)
-            else:
-                cq = g.Cout // 4
-                d = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
-                          kh=2, kw=2, stride=2, pad=0)
-                dwt = torch.zeros((g.Cin, 2, 2, cq), dtype=torch.float32, device=x.device)
-                wgrad(d, gz, x, dwt, None)
-                dw = dwt.permute(1, 2, 3, 0).reshape(g.Cout, 1, 1, g.Cin).contiguous()
-                if need_db:
-                    d1 = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=8, ldo=8,
-                               kh=2, kw=2, stride=2, pad=0)
-                    tmp = torch.zeros((8, 2, 2, cq), dtype=torch.float32, device=x.device)
-                    wgrad(d1, gz, _ones(g.B * g.H * g.W, x.device), tmp, None)
-                    db = tmp[0].reshape(g.Cout).contiguous()
+            dw, db = conv_wgrad(g, w, x, gz, need_db)
             if not need_dw:
                 dw = None
         return dx, dw, db, gres, None, None

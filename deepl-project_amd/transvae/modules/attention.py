@@ -21,7 +21,7 @@ from typing import Dict, Tuple
 import torch
 import torch.nn as nn
 
-from ..hip import ops
+from ..hip import fused, ops
 
 
 class RoPE2D(nn.Module):
@@ -104,13 +104,10 @@ class FlashAttentionWithRoPE(nn.Module):
 
     def forward_tokens(self, t: torch.Tensor, B: int, H: int, W: int, rms_weight: torch.Tensor, rms_eps: float) -> torch.Tensor:
         """t: [B*H*W, C] bf16 residual stream.  Returns t + attn(RMSNorm(t))."""
-        N = H * W
-        xh = ops.rms_ln_hat(t, rms_weight, rms_eps, self.norm_q.eps)
         w, b = self.folded_qkv()
-        qkv = ops.linear(xh, w, b)
         tab = self.rope.table(H, W) if self.use_rope else None
-        o = ops.attention(qkv.view(B, N, 3 * self.dim), tab, self.num_heads, self.scale)
-        return ops.linear(o.view(B * N, self.dim), self.proj.weight, self.proj.bias, residual=t)
+        return fused.AttnBranchFn.apply(t, rms_weight, w, b, self.proj.weight, self.proj.bias, tab, B, H * W,
+                                        self.num_heads, self.scale, rms_eps, self.norm_q.eps)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Reference-style call: x [B, C, H, W] (already normalised by the caller) -> attention output."""

@@ -15,7 +15,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..hip import ops
+from ..hip import fused, ops
 
 
 class ConvFFN(nn.Module):
@@ -46,8 +46,12 @@ class ConvFFN(nn.Module):
 
     def forward_tokens(self, t: torch.Tensor, B: int, H: int, W: int, rms_weight: torch.Tensor, rms_eps: float) -> torch.Tensor:
         """t: [B*H*W, d] bf16 residual stream.  Returns t + ffn(RMSNorm(t))."""
-        r = ops.rms_hat(t, rms_eps)
-        return self._tail(r, self.proj_in.weight * rms_weight[None, :], B, H, W, t)
+        hid, mid = self.hidden_dim, self.conv_hidden
+        c0, c2, c4 = self.conv[0], self.conv[2], self.conv[4]
+        return fused.ConvFFNBranchFn.apply(t, self.proj_in.weight * rms_weight[None, :], self.proj_in.bias,
+                                           c0.weight.view(mid, hid), c0.bias, c2.weight.permute(0, 2, 3, 1), c2.bias,
+                                           c4.weight.view(hid, mid), c4.bias, self.proj_out.weight, self.proj_out.bias,
+                                           B, H, W, rms_eps)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Reference-style call on [B, C, H, W] (input already normalised)."""

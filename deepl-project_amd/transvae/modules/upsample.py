@@ -15,7 +15,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..hip import ops
+from ..hip import fused, ops
 
 
 def _krsc(conv: nn.Conv2d) -> torch.Tensor:
@@ -35,13 +35,13 @@ class Downsample(nn.Module):
 
     def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
         C, Co = self.in_channels, self.out_channels
-        dc = None
+        wdc = bdc = None
         if self.use_dc_path:
             # pixel_unshuffle channel order is c*4 + dy*2 + dx  ->  taps (dy,dx), channel c
-            w = self.dc_conv.weight.view(Co, C, 2, 2).permute(0, 2, 3, 1)
-            dc = ops.conv(x, w, self.dc_conv.bias, None, "unshuf")
-        h = ops.conv(x, _krsc(self.main_path[0]), self.main_path[0].bias, None, "c3s1", "silu")
-        return ops.conv(h, _krsc(self.main_path[2]), self.main_path[2].bias, dc, "c3s2")
+            wdc = self.dc_conv.weight.view(Co, C, 2, 2).permute(0, 2, 3, 1)
+            bdc = self.dc_conv.bias
+        return fused.DownsampleFn.apply(x, _krsc(self.main_path[0]), self.main_path[0].bias,
+                                        _krsc(self.main_path[2]), self.main_path[2].bias, wdc, bdc)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from .blocks import nchw_call
@@ -62,14 +62,13 @@ class Upsample(nn.Module):
 
     def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
         C, Co = self.in_channels, self.out_channels
-        dc = None
+        wdc = bdc = None
         if self.use_dc_path:
             # pixel_shuffle reads output channel c*4 + dy*2 + dx  ->  GEMM columns ordered (dy,dx,c)
-            w = self.dc_conv.weight.view(Co, 2, 2, C).permute(1, 2, 0, 3).reshape(4 * Co, 1, 1, C)
-            b = self.dc_conv.bias.view(Co, 2, 2).permute(1, 2, 0).reshape(4 * Co)
-            dc = ops.conv(x, w, b, None, "shuf")
-        h = ops.conv(x, _krsc(self.main_path[1]), self.main_path[1].bias, None, "c3up", "silu")
-        return ops.conv(h, _krsc(self.main_path[3]), self.main_path[3].bias, dc, "c3s1")
+            wdc = self.dc_conv.weight.view(Co, 2, 2, C).permute(1, 2, 0, 3).reshape(4 * Co, 1, 1, C)
+            bdc = self.dc_conv.bias.view(Co, 2, 2).permute(1, 2, 0).reshape(4 * Co)
+        return fused.UpsampleFn.apply(x, _krsc(self.main_path[1]), self.main_path[1].bias,
+                                      _krsc(self.main_path[3]), self.main_path[3].bias, wdc, bdc)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from .blocks import nchw_call

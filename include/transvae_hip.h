@@ -78,6 +78,15 @@ int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, const float
                 const void* residual, void* pre_act, void* out, void* stream);
 
 /*
+ * Data gradient fused with the activation backward of the PREVIOUS layer:
+ *     out = (conv(x, w) + residual) * act'(aux_pre_act)
+ * i.e. the gradient w.r.t. the pre-activation tensor saved by the producing layer (aux_pre_act has the shape of
+ * out).  Replaces autograd's GELU / SiLU backward (conv.py:56,86; upsample.py:35,96) without a separate pass.
+ */
+int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const void* w, const void* residual,
+                        const void* aux_pre_act, int aux_act, void* out, void* stream);
+
+/*
  * Weight gradient of the same layer (fp32, ACCUMULATED into dw / dbias with atomics):
  *   dw[co][ky][kx][ci] += sum_p gy[p][co] * x_gathered[p][ky][kx][ci]
  *   dbias[co]          += sum_p gy[p][co]                       (dbias may be NULL)
