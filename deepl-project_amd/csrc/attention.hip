@@ -22,8 +22,17 @@ namespace {
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// ds_read_b64_tr_b16 via inline asm: the builtin makes hipcc (ROCm 7.2) drain vmcnt(0) before each transposed read
+// while an LDS-DMA is in flight, serialising the K/V DMA with compute.  Callers wait with lds_wait_all() before use.
 __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+    bf16x4 r;
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(a) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_wait_all() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -142,49 +151,64 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) s[kt] = mfma32(read_rows(kt_, kt * 32, st, lane), qf[st], s[kt]);
         }
-        // online softmax over this lane's 32 keys (+ the other half-wave's 32)
+        // V^T fragments of the whole 64-key block (transposed reads, asm): issued now, consumed after the softmax
+        bf16x8 vfr[2][2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) vfr[kt][ss][db] = read_cols<true>(vt_, kt * 32 + 16 * ss, db, lane);
+        // online softmax over this lane's 32 keys (+ the other half-wave's 32); scores stay unscaled, the scale
+        // rides in the exp2 FMA:  p = exp2(s*c2 - m*c2)
         const int kv0 = t * 64;
         const bool partial = kv0 + 64 > p.N;
+        if (partial) {   // only the last key block of a ragged sequence: mask keys >= N (wave-uniform branch)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= p.N) s[kt][r] = -INFINITY;
+                }
+        }
         float mloc = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[kt][r] * c2;
-                if (partial) {
-                    const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= p.N) v = -INFINITY;
-                }
-                s[kt][r] = v;
-                mloc = fmaxf(mloc, v);
-            }
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float mnew = fmaxf(m, mloc);
-        const float alpha = fexp2(m - mnew);
+        const float mc = mnew * c2;
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = fexp2(s[kt][r] - mnew);
+                const float pv = fexp2(fmaf(s[kt][r], c2, -mc));
                 s[kt][r] = pv;
                 rs += pv;
             }
         rs += __shfl_xor(rs, 32, 64);
-        l = l * alpha + rs;
-        m = mnew;
+        if (__any(mnew != m)) {   // some row's maximum moved: rescale the running sums (wave-uniform branch)
+            const float alpha = fexp2((m - mnew) * c2);
+            l *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            ot[0][i] *= alpha;
-            ot[1][i] *= alpha;
+            for (int i = 0; i < 16; ++i) {
+                ot[0][i] *= alpha;
+                ot[1][i] *= alpha;
+            }
         }
+        l += rs;
+        m = mnew;
+        lds_wait_all();
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 const bf16x8 pf = pack_acc(s[kt], ss);
 #pragma unroll
-                for (int db = 0; db < 2; ++db) ot[db] = mfma32(read_cols<true>(vt_, kt * 32 + 16 * ss, db, lane), pf, ot[db]);
+                for (int db = 0; db < 2; ++db) ot[db] = mfma32(vfr[kt][ss][db], pf, ot[db]);
             }
     }
     if (q_ok) {
@@ -198,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                             (bf16)(ot[db][4 * g + 3] * inv)};
                 *(bf16x4*)(orow + db * 32 + 8 * g + 4 * h) = v;
             }
-        if (h == 0) p.lse[((size_t)b * p.heads + head) * p.N + qi] = (m + __log2f(l)) * 0.6931471805599453f;
+        if (h == 0) p.lse[((size_t)b * p.heads + head) * p.N + qi] = (m * c2 + __log2f(l)) * 0.6931471805599453f;
     }
 }
 
@@ -299,20 +323,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
                 s = mfma32(read_rows(kt_, kt * 32, st, lane), qf[st], s);
                 dp = mfma32(read_rows(vt_, kt * 32, st, lane), gf[st], dp);
             }
+            bf16x8 kfr[2][2];   // K^T fragments (transposed asm reads): in flight during the exponentials
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = fexp2(s[r] * c2);
-                if (partial) {
+            for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) kfr[ss][db] = read_cols<false>(kt_, kt * 32 + 16 * ss, db, lane);
+            if (partial) {   // ragged last block: keys >= N must not contribute (P = 0): push their score to -inf
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
                     const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= p.N) pv = 0.f;
+                    if (key >= p.N) s[r] = -INFINITY;
                 }
-                s[r] = pv * dp[r];  // dS^T (without the factor `scale`)
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = fexp2(s[r] * c2) * dp[r];  // dS^T (without the factor `scale`)
+            lds_wait_all();
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 const bf16x8 df = pack_acc(s, ss);
 #pragma unroll
-                for (int db = 0; db < 2; ++db) dqt[db] = mfma32(read_cols<false>(kt_, kt * 32 + 16 * ss, db, lane), df, dqt[db]);
+                for (int db = 0; db < 2; ++db) dqt[db] = mfma32(kfr[ss][db], df, dqt[db]);
             }
         }
     }
@@ -407,6 +437,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
             s = mfma32(read_rows(qt_, 0, st, lane), kf[st], s);
             dp = mfma32(read_rows(gt_, 0, st, lane), vf[st], dp);
         }
+        bf16x8 gfr[2][2], qfr[2][2];   // dO^T and Q^T fragments (transposed asm reads)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                gfr[ss][db] = read_cols<false>(gt_, 16 * ss, db, lane);
+                qfr[ss][db] = read_cols<false>(qt_, 16 * ss, db, lane);
+            }
         // queries beyond N have Q = dO = 0, lse = delta = 0  =>  P = 1, dS = 0, and dO^T P adds 0
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -414,14 +452,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
             s[r] = pv;
             dp[r] = pv * dp[r];
         }
+        lds_wait_all();
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const bf16x8 pf = pack_acc(s, ss);
             const bf16x8 df = pack_acc(dp, ss);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                dvt[db] = mfma32(read_cols<false>(gt_, 16 * ss, db, lane), pf, dvt[db]);
-                dkt[db] = mfma32(read_cols<false>(qt_, 16 * ss, db, lane), df, dkt[db]);
+                dvt[db] = mfma32(gfr[ss][db], pf, dvt[db]);
+                dkt[db] = mfma32(qfr[ss][db], df, dkt[db]);
             }
         }
     }

@@ -77,13 +77,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
+    # attention post-processes its MFMA results with VALU work (softmax): keep them in VGPRs, or every block
+    # pays ~160 v_accvgpr_read/write copies (measured: 29 VALU instructions per MFMA before, profiles/)
+    extra = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
     procs = []
     objs = []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or not os.path.exists(o) or any(os.path.getmtime(o) < os.path.getmtime(d) for d in [s] + deps[len(srcs):]):
-            cmd = [hipcc] + flags + ["-c", s, "-o", o]
+            cmd = [hipcc] + flags + extra.get(os.path.basename(s), []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
