@@ -96,6 +96,20 @@ __device__ __forceinline__ float tv_act_grad_rt(int act, float z) {
 }
 
 // ---------------------------------------------------------------------------
+// LDS-DMA through a buffer descriptor (SGPR base + 32-bit per-lane offset + scalar offset)
+// ---------------------------------------------------------------------------
+constexpr int OOB_OFFSET = (int)0x80000000u;  // beyond any < 2 GiB buffer: the LDS-DMA writes zeros (probed: tools/probes)
+
+// lds[base + lane*16] = buf[voff + soff .. +16), or zeros if that range is outside [0, bytes).
+// The descriptor type only exists in the device pass (a kernel body naming it loses its host stub), hence the guard.
+__device__ __forceinline__ void buffer_load_lds16(const void* base, unsigned bytes, char* lds, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000),
+                                             TV_LDS(lds), 16, voff, soff, 0, 0);
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float tv_wave_sum(float v) {

@@ -46,17 +46,6 @@ struct IgemmArgs {
     unsigned x_bytes, w_bytes;  // MODE 2: extents of the two buffers (< 2 GiB)
 };
 
-constexpr int OOB_OFFSET = (int)0x80000000u;  // beyond any < 2 GiB buffer: the LDS-DMA writes zeros
-
-// 16-byte LDS-DMA through a buffer descriptor: lds[base + lane*16] = buf[voff + soff .. +16) or zeros if out of range.
-// The descriptor type only exists in the device pass (a kernel body naming it loses its host stub), hence the guard.
-__device__ __forceinline__ void buffer_load_lds16(const void* base, unsigned bytes, char* lds, int voff, int soff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000),
-                                             TV_LDS(lds), 16, voff, soff, 0, 0);
-#endif
-}
-
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

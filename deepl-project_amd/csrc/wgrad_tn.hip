@@ -29,6 +29,7 @@ struct WgradArgs {
     int h_out, w_out, c_out, ldo;
     int kh, kw, stride, pad, up_shift, dil_mask;
     int tiles_ci, chunk_px, hw_shift, w_shift, plain;
+    unsigned x_bytes;   // FAST path: extent of x in bytes
 };
 
 // physical 16-byte slot of logical chunk c in pixel-row r of a [32][TW] tile
@@ -83,7 +84,10 @@ constexpr int wgrad_min_waves() {
     return NWN == 4 ? 2 : (((TG / 32) * (TX / NWN / 16) <= 16) ? 3 : 1);
 }
 
-template <int TG, int TX, int BKP, int NWN>
+// FAST: stride-1 "same" convolution (or linear layer) on a power-of-two grid with both tensors < 2 GiB: staging by
+// buffer_load...lds with per-thread fixed offsets, the pixel advance in the scalar offset, the tap shift folded into
+// the descriptor base and padding / tails as out-of-range offsets (zeros) -- ~1/3 of the generic path's vector ALU work
+template <int TG, int TX, int BKP, int NWN, bool FAST>
 __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void wgrad_tn_kernel(const WgradArgs p) {
     constexpr int NW = 2 * NWN;                           // waves: 2 over co x NWN over ci
     constexpr int STAGES = 2;
@@ -142,8 +146,37 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
     const int hw = p.h_out * p.w_out;
     const int hv = p.h_in << p.up_shift, wv = p.w_in << p.up_shift;
 
+    // FAST-path constants
+    int g_voff[G_IT], x_voff[X_IT];
+#pragma unroll
+    for (int it = 0; it < G_IT; ++it) g_voff[it] = g_cok[it] ? (g_row[it] * p.ldo + g_col[it]) * 2 : OOB_OFFSET;
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) x_voff[it] = (x_row[it] * p.ldx + x_col[it]) * 2;
+    const int dty = ky - p.pad, dtx = kx - p.pad;
+    const long long dtap = ((long long)dty * p.w_in + dtx) * p.ldx;                 // tap shift in elements
+    const bf16* xb = p.x + dtap;
+    const unsigned xb_bytes = (unsigned)((long long)p.x_bytes - dtap * 2);
+    const unsigned g_bytes = (unsigned)((long long)p_end * p.ldo * 2);              // rows >= p_end read as zeros
+
     auto stage_issue = [&](int step, char* sbase) {
         const int pz = p_begin + step * BKP;
+        if constexpr (FAST) {
+#pragma unroll
+            for (int it = 0; it < G_IT; ++it) {
+                if (G_INSTR % NW != 0 && it * NW + wave >= G_INSTR) break;
+                buffer_load_lds16(p.gy, g_bytes, sbase + (it * NW + wave) * 1024, g_voff[it], pz * p.ldo * 2);
+            }
+#pragma unroll
+            for (int it = 0; it < X_IT; ++it) {
+                if (X_INSTR % NW != 0 && it * NW + wave >= X_INSTR) break;
+                const int px = pz + x_row[it];
+                const int r = px & (hw - 1);
+                const int uy = (r >> p.w_shift) + dty, ux = (r & (p.w_out - 1)) + dtx;
+                const bool ok = x_cok[it] && px < p_end && ((unsigned)uy < (unsigned)p.h_in) && ((unsigned)ux < (unsigned)p.w_in);
+                buffer_load_lds16(xb, xb_bytes, sbase + G_BYTES + (it * NW + wave) * 1024, ok ? x_voff[it] : OOB_OFFSET, pz * p.ldx * 2);
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
             if (G_INSTR % NW != 0 && it * NW + wave >= G_INSTR) break;
@@ -294,22 +327,28 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
 
 int g_wgrad_bkp = 0;     // 0 = heuristic (64), else 32 / 64 pixels per K-step
 int g_wgrad_blocks = 0;  // 0 = heuristic: target number of blocks for the split-K choice
+int g_wgrad_generic = 0; // 1 = never use the FAST staging path (A/B)
 int g_wgrad_waves = 0;   // 0 = heuristic (8 waves for the 192-wide co tile), 4 / 8 = force
 
-template <int TG, int TX, int BKP, int NWN>
-int launch_s(const WgradArgs& a, dim3 grid, hipStream_t s) {
+template <int TG, int TX, int BKP, int NWN, bool FAST>
+int launch_f(const WgradArgs& a, dim3 grid, hipStream_t s) {
     constexpr int BYTES = 2 * BKP * (TG + TX) * 2;
     if constexpr (BYTES > 160 * 1024 || (TX / NWN) % 16 != 0) {
         return -1;
     } else {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<TG, TX, BKP, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+            (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<TG, TX, BKP, NWN, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
             attr_done = true;
         }
-        hipLaunchKernelGGL((wgrad_tn_kernel<TG, TX, BKP, NWN>), grid, dim3(128 * NWN), BYTES, s, a);
+        hipLaunchKernelGGL((wgrad_tn_kernel<TG, TX, BKP, NWN, FAST>), grid, dim3(128 * NWN), BYTES, s, a);
         return 0;
     }
+}
+
+template <int TG, int TX, int BKP, int NWN>
+int launch_s(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    return (a.x_bytes != 0 && !g_wgrad_generic) ? launch_f<TG, TX, BKP, NWN, true>(a, grid, s) : launch_f<TG, TX, BKP, NWN, false>(a, grid, s);
 }
 
 template <int TG, int TX>
@@ -350,6 +389,14 @@ int launch(const WgradArgs& a0, hipStream_t s) {
     a.w_shift = log2_exact(a.w_out);
     a.hw_shift = log2_exact(a.h_out * a.w_out);
     if (a.hw_shift < 0) a.w_shift = -1;
+    {   // FAST staging path: stride-1 "same" conv / linear, power-of-two grid, 32-bit offsets
+        const long long xbytes = (long long)a.batch * a.h_in * a.w_in * a.ldx * 2;
+        const long long gbytes = (long long)a.M * a.ldo * 2;
+        const long long shift = ((long long)a.pad * a.w_in + a.pad) * a.ldx * 2;
+        const bool same = a.stride == 1 && a.up_shift == 0 && a.dil_mask == 0 && a.kh == a.kw && (a.kh == 1 || a.kh == 3) &&
+                          a.pad == a.kh / 2 && a.h_in == a.h_out && a.w_in == a.w_out && a.w_shift >= 0;
+        a.x_bytes = (same && xbytes + shift < (1ll << 31) && gbytes < (1ll << 31)) ? (unsigned)xbytes : 0u;
+    }
     // (w8: 8 waves, 2 per SIMD, for the 192-wide co tile: one wave's transposed-read phase overlaps the other's MFMAs)
     if (bkp == 64) {
         if (w8 && launch_s<TG, TX, 64, 4>(a, grid, s) == 0) return 0;
@@ -362,6 +409,8 @@ int launch(const WgradArgs& a0, hipStream_t s) {
 }  // namespace
 
 extern "C" int tv_set_wgrad_config(int bkp, int waves, int blocks) {
+    g_wgrad_generic = (blocks < 0) ? 1 : 0;
+    if (blocks < 0) blocks = 0;
     g_wgrad_bkp = bkp;
     g_wgrad_waves = waves;
     g_wgrad_blocks = blocks;
@@ -393,7 +442,7 @@ extern "C" int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy,
     a.h_out = d->h_out; a.w_out = d->w_out; a.c_out = d->c_out; a.ldo = d->ldo;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
     a.up_shift = d->up_shift; a.dil_mask = d->dil_mask;
-    a.tiles_ci = 1; a.chunk_px = 0; a.hw_shift = -1; a.w_shift = -1; a.plain = 0;
+    a.tiles_ci = 1; a.chunk_px = 0; a.hw_shift = -1; a.w_shift = -1; a.plain = 0; a.x_bytes = 0;
     hipStream_t s = (hipStream_t)stream;
     const bool g192 = (d->c_out % 192 == 0) && (d->c_out % 128 != 0);
     const bool x192 = (d->c_in % 192 == 0) && (d->c_in % 128 != 0);
