@@ -151,11 +151,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the TransVAE path has no CPU fallback")
+    # rehearsal hook: TV_BENCH_REHEARSE=1 runs all ranks on GPU 0 over gloo (RCCL refuses two ranks per device);
+    # it exists to exercise the N>1 code path on a one-GPU box and is never used for reported numbers
+    rehearse = os.environ.get("TV_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from transvae import TransVAE
     from transvae.hip import _lib
@@ -210,7 +218,7 @@ def main():
 
     if rank == 0:
         ips = args.global_batch * args.steps / dt
-        gf = TRAIN_GFLOP_PER_IMAGE.get(args.variant)
+        gf = TRAIN_GFLOP_PER_IMAGE.get(args.variant) if args.res == 256 else (31419.3 if (args.variant, args.res) == ("large", 512) else None)
         out = {
             "metric": "images/sec train step, TransVAE-Large f16d32 256px bs256",
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

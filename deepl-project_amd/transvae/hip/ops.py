@@ -228,9 +228,21 @@ def conv_dgrad(g: _Geo, w, gz, x_shape, residual=None, aux=None, aux_act: int = 
     return dx
 
 
-def conv_wgrad(g: _Geo, w, x, gz, need_db: bool):
-    """(dw in w's layout, dbias | None), fp32."""
+def conv_wgrad_alloc(g: _Geo, w, need_db: bool):
+    """Zeroed outputs of conv_wgrad (allocate on the stream that will consume them)."""
+    db = torch.zeros((g.Cout,), dtype=torch.float32, device=w.device) if need_db else None
+    if g.mode == "shuf":
+        return torch.zeros((g.Cin, 2, 2, g.Cout // 4), dtype=torch.float32, device=w.device), db
+    return torch.zeros_like(w, memory_format=torch.contiguous_format), db
+
+
+def conv_wgrad(g: _Geo, w, x, gz, need_db: bool, out=None):
+    """(dw in w's layout, dbias | None), fp32.  `out` = buffers from conv_wgrad_alloc (optional)."""
     dev = x.device
+    if out is not None and g.mode != "shuf":
+        dw, db = out
+        wgrad(g.fwd_desc(0), x, gz, dw, db)
+        return dw, db
     db = torch.zeros((g.Cout,), dtype=torch.float32, device=dev) if need_db else None
     if g.mode != "shuf":
         dw = torch.zeros_like(w, memory_format=torch.contiguous_format)
