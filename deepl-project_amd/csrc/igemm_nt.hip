@@ -376,7 +376,7 @@ bool g_use_dma = true;
 int g_cfg_bm = 0;      // 0 = heuristic, else 128 / 256
 int g_cfg_stages = 0;  // 0 = heuristic, else 2 / 3 / 4
 int g_cfg_bk = 0;      // 0 = largest that divides c_in, else 32 / 64
-int g_cfg_bn = 0;      // 256 = use 256-wide N tiles when c_out % 256 == 0
+int g_cfg_bn = 0;      // 0 = heuristic, 256 = 256-wide N tiles whenever c_out % 256 == 0, 128 = never
 int g_addr_mode = 0;   // 0 = buffer DMA when the tensors are < 2 GiB, 1 = force 64-bit global DMA
 
 constexpr int LDS_MAX = 160 * 1024;
@@ -421,16 +421,22 @@ int launch_big(const IgemmArgs& a, int bm, int stages, hipStream_t s) {
 template <int BK, int MODE>
 int launch_mode(IgemmArgs& a, hipStream_t s) {
     const int N = a.N;
-    const int bm = g_cfg_bm ? g_cfg_bm : 128;
     const int stages = g_cfg_stages ? g_cfg_stages : 2;
+    const long long m256 = (a.M + 255) / 256;
+    // Tile heuristic (tools/gemm_sweep.py, mb 64): 256x256 tiles (8 waves, 128x64 per wave: half the LDS bytes per
+    // MFMA) win 5-15 % where c_out % 256 == 0 and the grid still has >= 512 blocks; 256-row tiles help the N=192
+    // convolutions a little when M is huge; everything else runs 128-row tiles at 2-3 blocks per CU.
     if (N % 192 == 0 && N % 128 != 0) {
         a.tiles_n = N / 192;
+        const int bm = g_cfg_bm ? g_cfg_bm : (m256 * a.tiles_n >= 1024 ? 256 : 128);
         return launch_big<192, BK, MODE>(a, bm, stages, s);
     }
-    if (g_cfg_bn == 256 && N % 256 == 0) {
+    const bool want256 = g_cfg_bn ? (g_cfg_bn == 256) : (g_cfg_bm == 0 && m256 * (N / 256) >= 512);
+    if (want256 && N % 256 == 0) {
         a.tiles_n = N / 256;
-        return launch_big<256, BK, MODE>(a, bm, stages, s);
+        return launch_big<256, BK, MODE>(a, g_cfg_bm ? g_cfg_bm : 256, stages, s);
     }
+    const int bm = g_cfg_bm ? g_cfg_bm : 128;
     if (N > 64) {
         a.tiles_n = (N + 127) / 128;
         return launch_big<128, BK, MODE>(a, bm, stages, s);
