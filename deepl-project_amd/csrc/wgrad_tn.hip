@@ -327,6 +327,7 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
 
 int g_wgrad_bkp = 0;     // 0 = heuristic (64), else 32 / 64 pixels per K-step
 int g_wgrad_blocks = 0;  // 0 = heuristic: target number of blocks for the split-K choice
+int g_wgrad_tile256 = 0; // 0 = heuristic (linear layers only), 1 = always when both channel counts are multiples of 256, 2 = never
 int g_wgrad_generic = 0; // 1 = never use the FAST staging path (A/B)
 int g_wgrad_waves = 0;   // 0 = heuristic (8 waves for the 192-wide co tile), 4 / 8 = force
 
@@ -361,7 +362,7 @@ int launch(const WgradArgs& a0, hipStream_t s) {
     // split-K over pixel chunks.  Every partition re-adds the whole [Cout, taps*Cin] gradient with fp32 atomics
     // (1.3 TB/s chip wide, MI355X_MICROARCH "Global float atomics"), and blocks run in rounds of `slots` resident
     // blocks, so pick the split that minimises   rounds * (pixels per block) * t_pixel  +  atomic bytes / 1.3 TB/s.
-    const bool w8 = g_wgrad_waves != 4 && (TG == 192 || g_wgrad_waves == 8) && TX >= 128;
+    const bool w8 = g_wgrad_waves != 4 && (TG >= 192 || g_wgrad_waves == 8) && TX >= 128;
     const int per_cu = w8 ? 1 : (((TG / 32) * (TX / 32) <= 16) ? 3 : 2);
     const double slots = 256.0 * per_cu;
     const double t_px = 2.0 * TG * TX * slots / 750e12;                // seconds per pixel for one resident block
@@ -409,7 +410,8 @@ int launch(const WgradArgs& a0, hipStream_t s) {
 }  // namespace
 
 extern "C" int tv_set_wgrad_config(int bkp, int waves, int blocks) {
-    g_wgrad_generic = (blocks < 0) ? 1 : 0;
+    g_wgrad_generic = (blocks == -1) ? 1 : 0;
+    g_wgrad_tile256 = (blocks == -2) ? 1 : (blocks == -3 ? 2 : 0);
     if (blocks < 0) blocks = 0;
     g_wgrad_bkp = bkp;
     g_wgrad_waves = waves;
@@ -444,6 +446,12 @@ extern "C" int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy,
     a.up_shift = d->up_shift; a.dil_mask = d->dil_mask;
     a.tiles_ci = 1; a.chunk_px = 0; a.hw_shift = -1; a.w_shift = -1; a.plain = 0; a.x_bytes = 0;
     hipStream_t s = (hipStream_t)stream;
+    // 256x256 tiles (8 waves, 128x64 per wave): +5..20 % on linear layers, -9 % on 9-tap convolutions (gemm_sweep, mb 64)
+    if ((g_wgrad_tile256 == 1 || (g_wgrad_tile256 == 0 && d->kh * d->kw == 1)) && d->c_out % 256 == 0 && d->c_in % 256 == 0) {
+        launch<256, 256>(a, s);
+        TV_CHECK_LAUNCH("tv_wgrad_tn");
+        return TV_OK;
+    }
     const bool g192 = (d->c_out % 192 == 0) && (d->c_out % 128 != 0);
     const bool x192 = (d->c_in % 192 == 0) && (d->c_in % 128 != 0);
     const bool g64 = d->c_out <= 64, x64 = d->c_in <= 64;
