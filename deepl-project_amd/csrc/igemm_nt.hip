@@ -249,20 +249,44 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Fragment reads are software-pipelined against the MFMAs: where the registers allow (<= 80 fragment VGPRs) ALL reads
+    // of the K-step (both 32-deep halves) are issued up front, so the second half's ds_read_b128s fly under the first
+    // half's MFMAs instead of exposing their latency a second time; the 256x256 tile keeps one half in flight at a time.
+    constexpr bool PIPE_ALL = (MF + NF) * 4 * (BK / 32) <= 80;
     auto compute = [&](const char* sbase) {
+        if constexpr (PIPE_ALL) {
+            bf16x8 af[BK / 32][MF], bfr[BK / 32][NF];
 #pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
-            const int coff = ((kk * 4 + fq) ^ sw) * 16;
-            bf16x8 af[MF], bfr[NF];
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                const int coff = ((kk * 4 + fq) ^ sw) * 16;
 #pragma unroll
-            for (int i = 0; i < MF; ++i) af[i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
+                for (int i = 0; i < MF; ++i) af[kk][i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) bfr[j] = *(const bf16x8*)(sbase + b_row_off + j * 4 * (BK * 2) + coff);
+                for (int j = 0; j < NF; ++j) bfr[kk][j] = *(const bf16x8*)(sbase + b_row_off + j * 4 * (BK * 2) + coff);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep every read ahead of the MFMAs (the scheduler would sink them again)
 #pragma unroll
-            for (int i = 0; i < MF; ++i)
+            for (int kk = 0; kk < BK / 32; ++kk)
 #pragma unroll
-                for (int j = 0; j < NF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                const int coff = ((kk * 4 + fq) ^ sw) * 16;
+                bf16x8 af[MF], bfr[NF];
+#pragma unroll
+                for (int i = 0; i < MF; ++i) af[i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) bfr[j] = *(const bf16x8*)(sbase + b_row_off + j * 4 * (BK * 2) + coff);
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
