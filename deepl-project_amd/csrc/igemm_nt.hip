@@ -260,9 +260,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
             for (int kk = 0; kk < BK / 32; ++kk) {
                 const int coff = ((kk * 4 + fq) ^ sw) * 16;
 #pragma unroll
+#ifdef TV_ABL_NO_LDSREAD
+                for (int i = 0; i < MF; ++i) { af[kk][i] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(af[kk][i])); }
+#pragma unroll
+                for (int j = 0; j < NF; ++j) { bfr[kk][j] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(bfr[kk][j])); }
+#else
                 for (int i = 0; i < MF; ++i) af[kk][i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) bfr[kk][j] = *(const bf16x8*)(sbase + b_row_off + j * 4 * (BK * 2) + coff);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);   // keep every read ahead of the MFMAs (the scheduler would sink them again)
 #pragma unroll
@@ -270,8 +276,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
-                    for (int j = 0; j < NF; ++j)
+                    for (int j = 0; j < NF; ++j) {
+#ifdef TV_ABL_NO_MFMA
+                        asm volatile("" ::"v"(bfr[kk][j]), "v"(af[kk][i]));
+#else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+#endif
+                    }
         } else {
 #pragma unroll
             for (int kk = 0; kk < BK / 32; ++kk) {
@@ -303,8 +314,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
             if (LA >= 3 && younger == 2) wait_vmcnt<2 * NI>();
             else if (LA >= 2 && younger == 1) wait_vmcnt<NI>();
             else wait_vmcnt<0>();
+#ifndef TV_ABL_NO_BARRIER
             __builtin_amdgcn_s_barrier();
+#endif
+#ifndef TV_ABL_NO_DMA
             if (t + LA < nk) stage_issue(smem + nxt * STAGE);
+#endif
             compute(smem + cur * STAGE);
             cur = (cur + 1 == STAGES) ? 0 : cur + 1;
             nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;

@@ -15,7 +15,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))          # deepl-project_amd/
 CSRC = os.path.join(PKG_ROOT, "csrc")
-SO_PATH = os.path.join(_HERE, "libtransvae_hip.so")
+SO_PATH = os.environ.get("TV_HIP_SO") or os.path.join(_HERE, "libtransvae_hip.so")   # TV_HIP_SO: probe builds only
 
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 
