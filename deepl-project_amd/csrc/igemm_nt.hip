@@ -23,6 +23,8 @@
 // contiguous channel runs.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 struct IgemmArgs {
@@ -46,10 +48,57 @@ struct IgemmArgs {
     unsigned x_bytes, w_bytes;  // MODE 2: extents of the two buffers (< 2 GiB)
 };
 
+#ifndef TV_NO_PIPE2
+#define TV_NO_PIPE2 0
+#endif
+#ifndef TV_NO_LOADER_SPLIT
+#define TV_NO_LOADER_SPLIT 1   // DMA from waves 0-3 only (8-wave halo tiles): measured slower, kept for A/B
+#endif
+#ifndef TV_HALO_VOFF_REGS
+#define TV_HALO_VOFF_REGS 1
+#endif
+#ifndef TV_HALO_BURST
+#define TV_HALO_BURST 1       // 256x256 halo tile (single fragment set): DMA burst after the barrier, measured +5 % over threading
+#endif
+#ifndef TV_GENERIC_BURST
+#define TV_GENERIC_BURST 1    // same for the generic 256x256 tile (A/B on the 768-channel linear layers: +2-5 %)
+#endif
+#ifndef TV_SETPRIO
+#define TV_SETPRIO 1           // waves 4-7 (the arbitration losers on every SIMD) run at priority 1
+#endif
+#ifndef TV_NO_PINGPONG
+#define TV_NO_PINGPONG 1   // ping-pong main loop of the 8-wave tiles: measured, not (yet) a win -- see DESIGN.md
+#endif
+
+// f(integral_constant<int, I>) for I = I0 .. N-1: an unrolled loop whose index is usable as a template argument
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+
+// In-kernel phase timer (diagnostic builds only: -DTV_PROBE, tools/probes/igemm_phase_probe.py).  TV_T(i) adds the shader
+// cycles since the previous mark to counter i; one block in 509 dumps its per-wave counters at the end.
+#ifdef TV_PROBE
+__device__ unsigned long long* g_probe_dev = nullptr;
+#define TV_PROBE_DECL unsigned long long pr_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pr_t = __builtin_amdgcn_s_memtime();
+#define TV_T(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+                     const unsigned long long n__ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+                     __builtin_amdgcn_sched_barrier(0); pr_c[i] += n__ - pr_t; pr_t = n__; } while (0)
+#define TV_PROBE_DUMP(wave, lane) do { if (g_probe_dev && blockIdx.x % 509 == 0 && blockIdx.x / 509 < 16 && (lane) == 0) \
+        for (int i__ = 0; i__ < 8; ++i__) g_probe_dev[((blockIdx.x / 509) * 8 + (wave)) * 8 + i__] = pr_c[i__]; } while (0)
+#else
+#define TV_PROBE_DECL
+#define TV_T(i) do { } while (0)
+#define TV_PROBE_DUMP(wave, lane) do { } while (0)
+#endif
 
 template <int BK>
 __device__ __forceinline__ int swz_of(int i) {  // i: row index inside a 16-row fragment
@@ -59,12 +108,104 @@ __device__ __forceinline__ int swz_of(int i) {  // i: row index inside a 16-row 
         return (0x78 >> (2 * ((i >> 2) & 3))) & 3;
 }
 
+// Epilogue shared by the tile kernels.  The accumulator layout scatters a row over lanes (8-byte pieces); stored
+// directly the tile costs ~25 % of a K=1728 convolution (measured: K=64 launch 0.44 ms of 1.56 ms).  Instead every wave
+// parks its tile (+bias, bf16) in its own slice of the now idle stage buffers and streams it out row by row, 16 bytes
+// per lane: pre-activation store, activation, residual add and the output store are all full-line accesses.
+// m_of_row(r) = output pixel index (b, oy, ox linearised) of wave-tile row r; the caller has synchronised the block.
+template <int WTM, int WTN, class RowMap>
+__device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[WTM / 16][WTN / 16], char* smem, int wave, int lane,
+                                         int nw0, RowMap m_of_row) {
+    constexpr int MF = WTM / 16, NF = WTN / 16;
+    constexpr int ERS = WTN * 2 + 16;          // LDS row stride of the parked tile (16 B pad: bank spread)
+    constexpr int EB = WTM * ERS;              // bytes per wave
+    const int fi = lane & 15, fq = lane >> 4;
+    char* ebuf = smem + wave * EB;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int nl = fq * (4 * NF) + j * 4;
+            const int n = nw0 + nl;
+            f32x4 v = acc[i][j];
+            if (p.bias && n < p.N) {
+                const f32x4 bv = *(const f32x4*)(p.bias + n);
+                v += bv;
+            }
+            bf16x4 pv = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4*)(ebuf + (i * 16 + fi) * ERS + nl * 2) = pv;
+        }
+    }
+    // (same wave writes and reads: LDS executes a wave's accesses in order, no barrier needed)
+    constexpr int CPW = WTN / 8;               // 16-byte chunks per tile row
+    const int hw = p.h_out * p.w_out;
+    const int cq = p.N >> 2;
+#pragma unroll 2
+    for (int idx = lane; idx < WTM * CPW; idx += 64) {
+        const int r = idx / CPW, c8 = idx - r * CPW;
+        const int m = m_of_row(r);
+        const int n = nw0 + c8 * 8;
+        if (m >= p.M || n >= p.N) continue;
+        size_t off;
+        if (p.shuffle) {
+            const int sb = m / hw;
+            const int rr = m - sb * hw;
+            const int sy = rr / p.w_out, sx = rr - sy * p.w_out;
+            const int qs = n / cq;
+            const int c = n - qs * cq;
+            const size_t pix = ((size_t)sb * (2 * p.h_out) + 2 * sy + (qs >> 1)) * (2 * p.w_out) + 2 * sx + (qs & 1);
+            off = pix * p.ldo + c;
+        } else {
+            off = (size_t)m * p.ldo + n;
+        }
+        bf16x8 z = *(const bf16x8*)(ebuf + r * ERS + c8 * 16);
+        if (p.pre) *(bf16x8*)(p.pre + off) = z;
+        if (p.aux) {  // gradient w.r.t. a pre-activation: (acc + residual gradient) * act'(saved pre-activation)
+            const bf16x8 av = *(const bf16x8*)(p.aux + off);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)z[e];
+            if (p.res) {
+                const bf16x8 rv = *(const bf16x8*)(p.res + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (bf16)(v[e] * tv_act_grad_rt(p.aux_act, (float)av[e]));
+        } else if (p.act != TV_ACT_NONE || p.res) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tv_act_rt(p.act, (float)z[e]);
+            if (p.res) {
+                const bf16x8 rv = *(const bf16x8*)(p.res + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (bf16)v[e];
+        }
+        *(bf16x8*)(p.out + off) = z;
+    }
+}
+
 // MODE 0: register-staged loads + ds_write (bring-up / debugging)
 // MODE 1: global_load_lds with 64-bit per-lane addresses (tensors >= 2 GiB)
 // MODE 2: buffer_load ... lds: SGPR descriptor + 32-bit per-lane offset fixed per tap + scalar K offset; padding
 //         = out-of-range offset (the hardware writes zeros) -- no vector ALU work per DMA in the steady state
+// waves per SIMD the register allocation must leave room for: what the LDS footprint allows, at most 2 (the second
+// argument of __launch_bounds__; without it the compiler spends registers freely and the 4-wave tiles lose a block per CU)
+template <int BM, int BN, int NW, int BK, int STAGES>
+constexpr int igemm_min_waves() {
+    const int ring = STAGES * (BM + BN) * BK * 2 + (STAGES > 2 ? 1024 : 0);
+    const int epi = BM * (BN * 2 + 16 * (NW == 8 ? 2 : 2));
+    const int lds = ring > epi ? ring : epi;
+    const int blocks = 160 * 1024 / lds;
+    const int w = blocks * NW / 4;
+    return w >= 2 ? 2 : 1;
+}
+
 template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE>
-__global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs p) {
+__global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, BK, STAGES>())) void igemm_nt_kernel(const IgemmArgs p) {
     constexpr bool DMA = MODE != 0, BUF = MODE == 2;
     constexpr int NW = WGM * WGN;
     constexpr int CPR = BK / 8;     // 16-byte chunks per tile row
@@ -82,6 +223,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
     constexpr int NI = A_IT + B_IT;  // DMA instructions per thread and K-step
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    TV_PROBE_DECL
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -166,16 +308,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
 
     bf16x8 a_reg[DMA ? 1 : A_IT], b_reg[DMA ? 1 : B_IT];
 
-    // issue the global loads of K-step st_t (DMA: straight into LDS stage `sbase`)
-    auto stage_issue = [&](char* sbase) {
-        const int koff = st_ch * BK;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int j = it * NW + wave;
+    // issue piece q (0 .. NI-1: A pieces, then W pieces) of the global loads of K-step st_t (DMA: straight into LDS stage
+    // `sbase`).  Pieces are separate so that the main loop can thread them between the MFMAs: issued as one burst right
+    // after the barrier, the 7 DMAs of a wave wait ~120 cycles each for the address pipe (in-kernel timers,
+    // tools/probes/igemm_phase_probe.py) and hold up the wave's fragment reads and MFMAs behind them.
+    auto issue_piece = [&](char* sbase, int q) {
+        if (q < A_IT) {
+            const int it = q, j = it * NW + wave;
+            const int koff = st_ch * BK;
             if (A_INSTR % NW != 0 && j >= A_INSTR) {
                 if constexpr (PADDED && BUF) buffer_load_lds16(p.x, p.x_bytes, smem + STAGES * STAGE, OOB_OFFSET, 0);
                 else if constexpr (PADDED) __builtin_amdgcn_global_load_lds(TV_GLB(p.zeros + lane * 16), TV_LDS(smem + STAGES * STAGE), 16, 0, 0);
-                break;
+                return;
             }
             if constexpr (BUF) {
                 buffer_load_lds16(p.x, p.x_bytes, sbase + j * 1024, a_voff[it], koff * 2);
@@ -187,15 +331,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
                 if (a_ok[it]) v = *(const bf16x8*)(a_src[it] + koff);
                 a_reg[it] = v;
             }
-        }
-        const int kb = st_t * BK;
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int j = it * NW + wave;
+        } else {
+            const int it = q - A_IT, j = it * NW + wave;
+            const int kb = st_t * BK;
             if (B_INSTR % NW != 0 && j >= B_INSTR) {
                 if constexpr (PADDED && BUF) buffer_load_lds16(p.w, p.w_bytes, smem + STAGES * STAGE, OOB_OFFSET, 0);
                 else if constexpr (PADDED) __builtin_amdgcn_global_load_lds(TV_GLB(p.zeros + lane * 16), TV_LDS(smem + STAGES * STAGE), 16, 0, 0);
-                break;
+                return;
             }
             if constexpr (BUF) {
                 buffer_load_lds16(p.w, p.w_bytes, sbase + A_BYTES + j * 1024, b_voff[it], kb * 2);
@@ -208,7 +350,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
                 b_reg[it] = v;
             }
         }
-        // advance to the following K-step
+    };
+    auto stage_advance = [&]() {   // move the staging state to the following K-step
         ++st_t;
         if (++st_ch == cch) {
             st_ch = 0;
@@ -218,6 +361,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
             }
             if (st_t < nk) tap_setup();
         }
+    };
+    auto stage_issue = [&](char* sbase) {
+#pragma unroll
+        for (int q = 0; q < NI; ++q) issue_piece(sbase, q);
+        stage_advance();
     };
     // register-staged variant only: park the loaded registers in LDS stage `sbase`
     auto stage_write = [&](char* sbase) {
@@ -253,7 +401,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
     // of the K-step (both 32-deep halves) are issued up front, so the second half's ds_read_b128s fly under the first
     // half's MFMAs instead of exposing their latency a second time; the 256x256 tile keeps one half in flight at a time.
     constexpr bool PIPE_ALL = (MF + NF) * 4 * (BK / 32) <= 80;
-    auto compute = [&](const char* sbase) {
+    // `nbase` != nullptr: the DMA pieces of the K-step being staged go out between the MFMAs, one every GAP of them
+    constexpr int NMF = MF * NF * (BK / 32), GAP = NMF / NI > 0 ? NMF / NI : 1;
+    auto compute = [&](const char* sbase, char* nbase, auto issue_c) {
+        constexpr bool ISSUE = DMA && decltype(issue_c)::value;
         if constexpr (PIPE_ALL) {
             bf16x8 af[BK / 32][MF], bfr[BK / 32][NF];
 #pragma unroll
@@ -271,6 +422,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);   // keep every read ahead of the MFMAs (the scheduler would sink them again)
+            TV_T(3);
 #pragma unroll
             for (int kk = 0; kk < BK / 32; ++kk)
 #pragma unroll
@@ -282,7 +434,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
 #else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
 #endif
+                        const int idx = (kk * MF + i) * NF + j;
+                        if (ISSUE && idx % GAP == GAP - 1 && idx / GAP < NI) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_piece(nbase, idx / GAP);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
+            if constexpr (ISSUE) {
+#pragma unroll
+                for (int q = NMF / GAP; q < NI; ++q) issue_piece(nbase, q);
+                stage_advance();
+            }
         } else {
 #pragma unroll
             for (int kk = 0; kk < BK / 32; ++kk) {
@@ -295,34 +458,179 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
-                    for (int j = 0; j < NF; ++j)
+                    for (int j = 0; j < NF; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                        const int idx = (kk * MF + i) * NF + j;
+                        if (ISSUE && idx % GAP == GAP - 1 && idx / GAP < NI) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue_piece(nbase, idx / GAP);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+            }
+            if constexpr (ISSUE) {
+#pragma unroll
+                for (int qq = NMF / GAP; qq < NI; ++qq) issue_piece(nbase, qq);
+                stage_advance();
             }
         }
     };
 
     // ---- main loop -------------------------------------------------------------------------
-    if constexpr (DMA) {
+    // 8-wave tiles: waves w and w+4 share a SIMD.  With one barrier per K-step all eight issue their fragment reads
+    // together and every MFMA pipe idles until the LDS has served them (ablation: the reads cost 0.25-0.4 ms of 2.7).
+    // Ping-pong instead: the block runs in HALF-steps, group 0 (waves 0-3) reads the fragments of step t while group 1
+    // multiplies step t-1, then they swap, so each SIMD always has one wave in its MFMA phase.
+    constexpr bool PINGPONG = DMA && STAGES == 2 && NW == 8 && PIPE_ALL && !TV_NO_PINGPONG;
+    // Register-pipelined loop (in-kernel timers: after a K-step barrier all waves read their fragments at once, ~640 LDS
+    // cycles during which no MFMA issues).  Each wave keeps two half-step fragment sets: while the MFMAs of one half run,
+    // the reads of the next half are in flight, ACROSS the stage boundary.  The block barrier therefore sits in the middle
+    // of a K-step: every wave has read all of stage t (second half issued before the first half's MFMAs), stage t+1 has
+    // landed, and stage t's buffer is refilled with stage t+STAGES between the MFMAs that follow.
+    constexpr bool PIPE2 = DMA && PIPE_ALL && BK == 64 && !PINGPONG && !TV_NO_PIPE2;
+    if constexpr (PIPE2) {
+        bf16x8 f0a[MF], f0b[NF], f1a[MF], f1b[NF];
+        auto read_half = [&](const char* sbase, int kk, bf16x8 (&fa)[MF], bf16x8 (&fb)[NF]) {
+            const int coff = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) fa[i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) fb[j] = *(const bf16x8*)(sbase + b_row_off + j * 4 * (BK * 2) + coff);
+        };
+        constexpr int HMF = MF * NF, HGAP = HMF / NI > 0 ? HMF / NI : 1;
+        const int dphase = __builtin_amdgcn_readfirstlane(wave % HGAP);
+        auto mfma_half = [&](const bf16x8 (&fa)[MF], const bf16x8 (&fb)[NF], char* nbase, auto issue_c) {
+            constexpr bool ISSUE = decltype(issue_c)::value;
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    const int idx = i * NF + j;   // DMA slots staggered by wave (see conv3x3_halo_kernel)
+                    if (ISSUE && idx / HGAP < NI && idx % HGAP == dphase) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(nbase, idx / HGAP);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            if constexpr (ISSUE) {
+#pragma unroll
+                for (int q = HMF / HGAP; q < NI; ++q) issue_piece(nbase, q);
+                stage_advance();
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s)
+            if (s < nk) stage_issue(smem + s * STAGE);
+        if (nk >= STAGES) wait_vmcnt<(STAGES - 1) * NI>();   // stage 0 landed
+        else wait_vmcnt<0>();
+        if (TV_SETPRIO && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_barrier();
+        read_half(smem, 0, f0a, f0b);
+        int cur = 0, t = 0;
+        auto step = [&](auto issue_c, auto last_c) {
+            char* const sb = smem + cur * STAGE;
+            char* const sn = smem + ((cur + 1 == STAGES) ? 0 : cur + 1) * STAGE;
+            read_half(sb, 1, f1a, f1b);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(f0a, f0b, nullptr, std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!decltype(last_c)::value) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of stage t are done: its buffer may be refilled
+                // stage t+1 landed; stages t+2 .. t+STAGES-1 may still be in flight (fewer in the drain)
+                if (STAGES >= 3 && t + 2 < nk) wait_vmcnt<(STAGES - 2) * NI>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                read_half(sn, 0, f0a, f0b);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mfma_half(f1a, f1b, sb, issue_c);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+        };
+        for (; t + STAGES < nk; ++t) step(std::true_type{}, std::false_type{});
+        for (; t + 1 < nk; ++t) step(std::false_type{}, std::false_type{});
+        step(std::false_type{}, std::true_type{});
+    } else if constexpr (PINGPONG) {
+        // Both groups run the same code, group 1 one barrier behind.  Phase k lies between block barriers k and k+1:
+        //   group 0: reads step t in phase 2t,   multiplies it in phase 2t+1
+        //   group 1: reads step t in phase 2t+1, multiplies it in phase 2t+2
+        // The buffer of step t+1 is last read in phase 2t-1 and first read in phase 2t+2: every wave issues its share of
+        // that DMA in phase 2t and waits for it at the end of phase 2t+1.
+        const int grp = wave >> 2;
+        stage_issue(smem);
+        wait_vmcnt<0>();
+        if (grp == 1) {
+            __builtin_amdgcn_s_barrier();
+            if (1 < nk) stage_issue(smem + STAGE);
+        }
+        for (int t = 0; t < nk; ++t) {
+            __builtin_amdgcn_s_barrier();
+            if (grp == 0 && t + 1 < nk) stage_issue(smem + ((t + 1) & 1) * STAGE);
+            const char* sbase = smem + (t & 1) * STAGE;
+            bf16x8 af[BK / 32][MF], bfr[BK / 32][NF];
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                const int coff = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+                for (int i = 0; i < MF; ++i) af[kk][i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) bfr[kk][j] = *(const bf16x8*)(sbase + b_row_off + j * 4 * (BK * 2) + coff);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer may be refilled after the next barrier
+            if (grp == 1) wait_vmcnt<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if (grp == 1 && t + 2 < nk) stage_issue(smem + (t & 1) * STAGE);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk)
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+            if (grp == 0) wait_vmcnt<0>();
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+    } else if constexpr (DMA) {
         constexpr int LA = STAGES - 1;  // K-steps of lookahead
 #pragma unroll
         for (int s = 0; s < LA; ++s)
             if (s < nk) stage_issue(smem + s * STAGE);
-        int cur = 0, nxt = LA % STAGES;
-        for (int t = 0; t < nk; ++t) {
-            // K-step t must have landed; up to min(LA-1, nk-1-t) younger K-steps may stay in flight
-            const int younger = min(LA - 1, nk - 1 - t);
-            if (LA >= 3 && younger == 2) wait_vmcnt<2 * NI>();
-            else if (LA >= 2 && younger == 1) wait_vmcnt<NI>();
-            else wait_vmcnt<0>();
+        int cur = 0, nxt = LA % STAGES, t = 0;
+        // steady state: K-step t must have landed, the LA-1 younger ones may stay in flight; the pieces of K-step t+LA go
+        // out between the MFMAs of step t (into the buffer every wave left before this barrier)
+        for (; t + LA < nk; ++t) {
+            wait_vmcnt<(LA - 1) * NI>();
+            TV_T(0);
 #ifndef TV_ABL_NO_BARRIER
             __builtin_amdgcn_s_barrier();
 #endif
-#ifndef TV_ABL_NO_DMA
-            if (t + LA < nk) stage_issue(smem + nxt * STAGE);
+            TV_T(1);
+#if TV_GENERIC_BURST
+            stage_issue(smem + nxt * STAGE);
+            compute(smem + cur * STAGE, nullptr, std::false_type{});
+#elif !defined(TV_ABL_NO_DMA)
+            compute(smem + cur * STAGE, smem + nxt * STAGE, std::true_type{});
+#else
+            compute(smem + cur * STAGE, nullptr, std::false_type{});
 #endif
-            compute(smem + cur * STAGE);
+            TV_T(4);
             cur = (cur + 1 == STAGES) ? 0 : cur + 1;
             nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
+        }
+        for (; t < nk; ++t) {   // drain: nothing left to issue
+            if (LA >= 2 && nk - 1 - t == 1) wait_vmcnt<NI>();
+            else wait_vmcnt<0>();
+            TV_T(0);
+#ifndef TV_ABL_NO_BARRIER
+            __builtin_amdgcn_s_barrier();
+#endif
+            TV_T(1);
+            compute(smem + cur * STAGE, nullptr, std::false_type{});
+            TV_T(4);
+            cur = (cur + 1 == STAGES) ? 0 : cur + 1;
         }
     } else {
         stage_issue(smem);
@@ -330,85 +638,361 @@ __global__ __launch_bounds__(WGM* WGN * 64) void igemm_nt_kernel(const IgemmArgs
         for (int t = 0; t < nk; ++t) {
             __syncthreads();
             if (t + 1 < nk) stage_issue(nullptr);
-            compute(smem + (t & 1) * STAGE);
+            compute(smem + (t & 1) * STAGE, nullptr, std::false_type{});
             if (t + 1 < nk) stage_write(smem + ((t + 1) & 1) * STAGE);
         }
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
-    // The accumulator layout scatters a row over lanes (8-byte pieces); stored directly the tile costs ~25 % of a
-    // K=1728 convolution (measured: K=64 launch 0.44 ms of 1.56 ms).  Instead every wave parks its tile (+bias,
-    // bf16) in its own slice of the now idle stage buffers and streams it out row by row, 16 bytes per lane:
-    // pre-activation store, activation, residual add and the output store are all full-line accesses.
-    constexpr int ERS = WTN * 2 + 16;          // LDS row stride of the parked tile (16 B pad: bank spread)
-    constexpr int EB = WTM * ERS;              // bytes per wave
+    if (TV_SETPRIO) __builtin_amdgcn_s_setprio(0);
+    TV_T(5);
     __syncthreads();                           // every wave is done reading the stage buffers
-    char* ebuf = smem + wave * EB;
+    const int mrow0 = m0 + wm * WTM;
+    epilogue<WTM, WTN>(p, acc, smem, wave, lane, n0 + wn * WTN, [&](int r) { return mrow0 + r; });
+    TV_T(6);
+    TV_PROBE_DUMP(wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions (and their data gradients): halo-tile variant.
+//
+// Ablation of the generic kernel on its dominant shape (tools/probes/build_ablations.sh: 2.69 ms as is, 1.95 ms without
+// the DMA, 1.65 ms with MFMA + epilogue only) shows the L2 -> LDS fill rate, not the MFMA or the LDS reads, to be the
+// bound: the generic kernel fetches every activation row once per tap.  Here a block owns a TH x 16 SPATIAL tile and
+// stages, per 64-channel chunk, the (TH+2) x 18 halo once (1.27x / 1.41x the tile instead of 9x); the nine taps are
+// nine shifted fragment views of that one LDS image.  Weights stream as before, one [BN][64] slab per tap.
+//
+//   K order: channel chunk outer, tap inner.  Halo chunk c+1 is fetched piecewise under the taps of chunk c.
+//   LDS image of the halo: pixel-major rows of 128 B, 16-byte chunk index XORed with (halo pixel & 7): every
+//   16-pixel run of a halo row is conflict-free for ds_read_b128 whatever the tap shift.
+//   Zero padding: halo pixels outside the image use an out-of-range buffer offset (the DMA writes zeros).
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int BST>
+__global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const IgemmArgs p) {
+    constexpr int BK = 64, NW = WGM * WGN, TW = 16, TH = BM / TW, HWD = TW + 2, HP = (TH + 2) * HWD;
+    constexpr int A_PIECES = (HP * 8 + 63) / 64;             // 1 KiB DMA pieces per halo chunk (8 pixels each)
+    constexpr int WTM = BM / WGM, WTN = BN / WGN, MF = WTM / 16, NF = WTN / 16;
+    constexpr bool PIPE_ALL = (MF + NF) * 4 * (BK / 32) <= 80;
+    // Loader waves.  Waves w and w+4 of an 8-wave block share a SIMD and run in lockstep between barriers; a DMA issued by
+    // all eight at the same point of the MFMA stream queues ~120 cycles at the address pipe (64 B/clk per CU) and stalls
+    // BOTH waves of every SIMD.  In the pipelined loop only waves 0 .. NWL-1 issue DMAs: while one of them waits at the
+    // address pipe its partner keeps the MFMA pipe busy.
+    constexpr int NWL = (NW == 8 && PIPE_ALL && !TV_NO_PIPE2 && !TV_NO_LOADER_SPLIT) ? 4 : NW;
+    constexpr int A_IT = (A_PIECES + NWL - 1) / NWL;         // halo pieces per loader wave and chunk
+    constexpr int A_BYTES = A_PIECES * 1024, B_BYTES = BN * BK * 2;
+    constexpr int B_INSTR = BN / 8, B_IT = B_INSTR / NWL;
+    static_assert(BST == 2 || BST == 3, "weight ring depth");
+    static_assert(B_INSTR % NWL == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile shape");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    TV_PROBE_DECL
+    char* const a_buf = smem;                  // [2][A_BYTES]
+    char* const b_buf = smem + 2 * A_BYTES;    // [BST][B_BYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int tile_n = blockIdx.x % p.tiles_n;
+    const int tile_m = blockIdx.x / p.tiles_n;
+    const int n0 = tile_n * BN;
+    const int tiles_x = p.w_out / TW, tiles_y = p.h_out / TH;
+    const int b = tile_m / (tiles_x * tiles_y);
+    const int trem = tile_m - b * (tiles_x * tiles_y);
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+
+    // ---- staging bookkeeping ---------------------------------------------------------------------------------------------
+    // halo piece j covers halo pixels 8j .. 8j+7 (lane / 8) x 8 chunks (lane % 8); the per-lane source offset is rebuilt for
+    // each piece (a dozen VALU operations per KiB) instead of parking A_IT registers for the whole loop
+    const int a_c16 = ((lane & 7) ^ ((lane >> 3) & 7)) * 16;   // (8j + lane/8) & 7 == (lane/8) & 7
+    auto a_voff_of = [&](int j) {
+        int l8 = lane >> 3;
+        asm volatile("" : "+v"(l8));   // loop-invariant otherwise: the compiler would hoist all A_IT offsets and spill
+        const int hp = j * 8 + l8;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = hp < HP && (unsigned)iy < (unsigned)p.h_in && (unsigned)ix < (unsigned)p.w_in;
+        return ok ? ((b * p.h_in + iy) * p.w_in + ix) * p.ldx * 2 + a_c16 : OOB_OFFSET;
+    };
+    // weight piece j covers rows 8j .. 8j+7 of the [BN][64] slab; its source offset is rebuilt per piece as well
+    auto b_voff_of = [&](int j) {
+        int l8 = lane >> 3;
+        asm volatile("" : "+v"(l8));
+        const int row = j * 8 + l8;
+        const int rl = row % WTN;
+        const int fr = ((rl / (4 * NF)) << 2) | (row & 3);
+        const int c = ((lane & 7) ^ swz_of<BK>(fr)) * 8;
+        const int n = n0 + row;
+        return (n < p.N) ? (n * p.K + c) * 2 : OOB_OFFSET;
+    };
+    const int cch = p.c_in / BK;
+
+    // where the registers allow, the offsets are computed once (the recomputation is ~12 VALU operations per piece in the
+    // middle of the MFMA stream)
+    constexpr bool VOFF_REGS = TV_HALO_VOFF_REGS && (MF * NF * 4 + (MF + NF) * 8 <= 160 || BST == 3 || !PIPE_ALL);   // (256x192, ring 2 would spill)
+    int a_voff_r[VOFF_REGS ? A_IT : 1], b_voff_r[VOFF_REGS ? B_IT : 1];
+    if constexpr (VOFF_REGS) {
 #pragma unroll
-    for (int i = 0; i < MF; ++i) {
+        for (int it = 0; it < A_IT; ++it) a_voff_r[it] = a_voff_of(it * NWL + wave);
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const int nl = fq * (4 * NF) + j * 4;
-            const int n = n0 + wn * WTN + nl;
-            f32x4 v = acc[i][j];
-            if (p.bias && n < p.N) {
-                const f32x4 bv = *(const f32x4*)(p.bias + n);
-                v += bv;
-            }
-            bf16x4 pv = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *(bf16x4*)(ebuf + (i * 16 + fi) * ERS + nl * 2) = pv;
-        }
+        for (int it = 0; it < B_IT; ++it) b_voff_r[it] = b_voff_of(it * NWL + wave);
     }
-    // (same wave writes and reads: LDS executes a wave's accesses in order, no barrier needed)
-    constexpr int CPW = WTN / 8;               // 16-byte chunks per tile row
-    const int hw = p.h_out * p.w_out;
-    const int cq = p.N >> 2;
-#pragma unroll 2
-    for (int idx = lane; idx < WTM * CPW; idx += 64) {
-        const int r = idx / CPW, c8 = idx - r * CPW;
-        const int m = m0 + wm * WTM + r;
-        const int n = n0 + wn * WTN + c8 * 8;
-        if (m >= p.M || n >= p.N) continue;
-        size_t off;
-        if (p.shuffle) {
-            const int sb = m / hw;
-            const int rr = m - sb * hw;
-            const int sy = rr / p.w_out, sx = rr - sy * p.w_out;
-            const int qs = n / cq;
-            const int c = n - qs * cq;
-            const size_t pix = ((size_t)sb * (2 * p.h_out) + 2 * sy + (qs >> 1)) * (2 * p.w_out) + 2 * sx + (qs & 1);
-            off = pix * p.ldo + c;
+    auto issue_a = [&](char* dst, int it, int ch) {   // piece `it` of this (loader) wave, channel chunk ch
+        const int j = it * NWL + wave;
+        if (j < A_PIECES) buffer_load_lds16(p.x, p.x_bytes, dst + j * 1024, VOFF_REGS ? a_voff_r[VOFF_REGS ? it : 0] : a_voff_of(j), ch * (BK * 2));
+    };
+    auto issue_b_piece = [&](char* dst, int it, int koff) {
+        buffer_load_lds16(p.w, p.w_bytes, dst + (it * NWL + wave) * 1024, VOFF_REGS ? b_voff_r[VOFF_REGS ? it : 0] : b_voff_of(it * NWL + wave), koff);
+    };
+    auto issue_b = [&](char* dst, int tap, int ch) {
+        const int koff = (tap * p.c_in + ch * BK) * 2;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) issue_b_piece(dst, it, koff);
+    };
+
+    // ---- fragment addressing -------------------------------------------------------------------------------------------
+    const int fi = lane & 15, fq = lane >> 4;
+    const int sw = swz_of<BK>(fi);
+    const int hp_base = (wm * MF) * HWD + fi;     // halo pixel of (fragment 0, tap (0,0)); fragment i adds i*HWD, tap adds dy*HWD+dx
+    const int b_row_off = (wn * WTN + (fi >> 2) * (4 * NF) + (fi & 3)) * (BK * 2);
+
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // issue(q), q = 0 .. B_IT: the DMA pieces that go out during this step (halo piece first, then the weight slab), one
+    // every GAP MFMAs -- a burst after the barrier would hold the wave's own reads and MFMAs behind the address pipe
+    constexpr int NMF = MF * NF * (BK / 32), NIH = B_IT + 1, GAP = NMF / NIH;
+    auto compute = [&](const char* abase, const char* bbase, int toff, auto issue) {
+        // the fragment addresses of a tap are cheap to rebuild and loop-invariant: left alone, the compiler hoists all
+        // 9 x MF x 2 of them out of the chunk loop and spills; the opaque copy pins the arithmetic to this tap
+        int hpb = hp_base;
+        asm volatile("" : "+v"(hpb));
+        int a_off[MF], a_sw[MF];
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int hp = hpb + i * HWD + toff;
+            a_off[i] = hp * (BK * 2);
+            a_sw[i] = hp & 7;
+        }
+        if constexpr (PIPE_ALL) {
+            bf16x8 af[BK / 32][MF], bfr[BK / 32][NF];
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i) af[kk][i] = *(const bf16x8*)(abase + a_off[i] + (((kk * 4 + fq) ^ a_sw[i]) << 4));
+                const int coff = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+                for (int j = 0; j < NF; ++j) bfr[kk][j] = *(const bf16x8*)(bbase + b_row_off + j * 4 * (BK * 2) + coff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            TV_T(3);
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk)
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+                        const int idx = (kk * MF + i) * NF + j;
+                        if (idx % GAP == GAP - 1 && idx / GAP < NIH) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue(idx / GAP);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
         } else {
-            off = (size_t)m * p.ldo + n;
-        }
-        bf16x8 z = *(const bf16x8*)(ebuf + r * ERS + c8 * 16);
-        if (p.pre) *(bf16x8*)(p.pre + off) = z;
-        if (p.aux) {  // gradient w.r.t. a pre-activation: (acc + residual gradient) * act'(saved pre-activation)
-            const bf16x8 av = *(const bf16x8*)(p.aux + off);
-            float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (float)z[e];
-            if (p.res) {
-                const bf16x8 rv = *(const bf16x8*)(p.res + off);
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                bf16x8 af[MF], bfr[NF];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                for (int i = 0; i < MF; ++i) af[i] = *(const bf16x8*)(abase + a_off[i] + (((kk * 4 + fq) ^ a_sw[i]) << 4));
+                const int coff = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+                for (int j = 0; j < NF; ++j) bfr[j] = *(const bf16x8*)(bbase + b_row_off + j * 4 * (BK * 2) + coff);
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                        const int idx = (kk * MF + i) * NF + j;
+                        if (idx % GAP == GAP - 1 && idx / GAP < NIH) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue(idx / GAP);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (bf16)(v[e] * tv_act_grad_rt(p.aux_act, (float)av[e]));
-        } else if (p.act != TV_ACT_NONE || p.res) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = tv_act_rt(p.act, (float)z[e]);
-            if (p.res) {
-                const bf16x8 rv = *(const bf16x8*)(p.res + off);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (bf16)v[e];
         }
-        *(bf16x8*)(p.out + off) = z;
+    };
+
+    // ---- main loop ------------------------------------------------------------------------------------------------------
+    if constexpr (PIPE_ALL && !TV_NO_PIPE2) {
+        // Register-pipelined like the generic kernel: two half-step (32-deep) fragment sets per wave; the block barrier sits
+        // between the halves of a step, when every wave has read all of step t.  After it the weight slot of step t is
+        // refilled with step t+BST and the halo pieces of the next chunk go out (taps 0-5), threaded between the MFMAs of
+        // the loader waves.
+        //   DMA order per step: [slab pieces x B_IT, halo pieces x <= A_PT].  At the barrier of step t slab t+1 must have
+        //   landed: BST 2: only the halo pieces of step t-1 are younger;  BST 3: halo(t-2), slab(t+2), halo(t-1) are.
+        constexpr int ATAPS = 6, A_PT = (A_IT + ATAPS - 1) / ATAPS;
+        constexpr auto nsure = [](int tap) {   // halo pieces of a tap that every loader wave issues
+            int n = 0;
+            for (int it = tap * A_PT; it < tap * A_PT + A_PT; ++it)
+                if (tap >= 0 && tap < ATAPS && it < A_IT && (it + 1) * NWL <= A_PIECES) ++n;
+            return n;
+        };
+        constexpr int HMF = MF * NF, NIS = B_IT + A_PT, HGAP = HMF / NIS;
+        static_assert(HGAP >= 1, "more DMA pieces than MFMAs in a half-step");
+        bf16x8 f0a[MF], f0b[NF], f1a[MF], f1b[NF];
+        auto read_half = [&](const char* abase, const char* bbase, int toff, int kk, bf16x8 (&fa)[MF], bf16x8 (&fb)[NF]) {
+            int hpb = hp_base;
+            asm volatile("" : "+v"(hpb));   // pin the address arithmetic to this tap (see compute)
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const int hp = hpb + i * HWD + toff;
+                fa[i] = *(const bf16x8*)(abase + hp * (BK * 2) + (((kk * 4 + fq) ^ (hp & 7)) << 4));
+            }
+            const int coff = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) fb[j] = *(const bf16x8*)(bbase + b_row_off + j * 4 * (BK * 2) + coff);
+        };
+        auto mfma_half = [&](const bf16x8 (&fa)[MF], const bf16x8 (&fb)[NF], auto issue) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    const int idx = i * NF + j;
+                    if (idx % HGAP == HGAP - 1 && idx / HGAP < NIS) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue(idx / HGAP);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        };
+        auto run = [&](auto loader_c) {
+            constexpr bool LOADER = decltype(loader_c)::value;
+            if constexpr (LOADER) {
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) issue_a(a_buf, it, 0);
+#pragma unroll
+                for (int sl = 0; sl < BST; ++sl) issue_b(b_buf + sl * B_BYTES, sl, 0);
+                wait_vmcnt<(BST - 1) * B_IT>();
+            }
+            if (TV_SETPRIO && NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_barrier();
+            read_half(a_buf, b_buf, 0, 0, f0a, f0b);
+            int bcur = 0;
+            for (int ch = 0; ch < cch; ++ch) {
+                const char* acur = a_buf + (ch & 1) * A_BYTES;
+                char* anxt = a_buf + ((ch + 1) & 1) * A_BYTES;
+                const bool more = ch + 1 < cch;
+                static_for<0, 9>([&](auto tap_c) {
+                    constexpr int tap = decltype(tap_c)::value;
+                    char* const bslot = b_buf + bcur * B_BYTES;
+                    const char* const bnext = b_buf + ((bcur + 1 == BST) ? 0 : bcur + 1) * B_BYTES;
+                    read_half(acur, bslot, (tap / 3) * HWD + (tap % 3), 1, f1a, f1b);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_half(f0a, f0b, [](int) {});
+                    __builtin_amdgcn_sched_barrier(0);
+                    TV_T(3);
+                    if (tap < 8 || more) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of step t are done: its slab slot may be refilled
+                        if constexpr (LOADER) {
+                            if (more) wait_vmcnt<(BST == 3 ? nsure(tap - 2) + B_IT : 0) + nsure(tap - 1)>();
+                            else wait_vmcnt<(BST == 3 && tap <= 6) ? B_IT : 0>();
+                        }
+                        TV_T(0);
+                        __builtin_amdgcn_s_barrier();
+                        TV_T(1);
+                        if (tap < 8) read_half(acur, bnext, ((tap + 1) / 3) * HWD + ((tap + 1) % 3), 0, f0a, f0b);
+                        else read_half(anxt, bnext, 0, 0, f0a, f0b);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (LOADER) {
+                        const bool b_go = (tap + BST < 9) || more;
+                        const int b_koff = ((tap + BST < 9) ? (tap + BST) * p.c_in + ch * BK : (tap + BST - 9) * p.c_in + (ch + 1) * BK) * 2;
+                        mfma_half(f1a, f1b, [&](int q) {
+                            if (q < B_IT) {
+                                if (b_go) issue_b_piece(bslot, q, b_koff);
+                            } else if (tap < ATAPS && tap * A_PT + (q - B_IT) < A_IT && more) {
+                                issue_a(anxt, tap * A_PT + (q - B_IT), ch + 1);
+                            }
+                        });
+                    } else {
+                        mfma_half(f1a, f1b, [](int) {});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    TV_T(4);
+                    bcur = (bcur + 1 == BST) ? 0 : bcur + 1;
+                });
+            }
+        };
+        if constexpr (NWL == NW) {
+            run(std::true_type{});
+        } else {
+            if (wave < NWL) run(std::true_type{});
+            else run(std::false_type{});
+        }
+    } else {
+        // ---- main loop: one barrier per (chunk, tap).  The weight slab of step t + BST - 1 and one halo piece of the next
+        // chunk are issued at step t, the halo piece FIRST: vmcnt counts in order, so "at most B_IT outstanding" (BST = 3)
+        // means everything but the youngest weight slab -- in particular step t's slab and every older halo piece -- has landed.
+        constexpr int LA = BST - 1;
+    #pragma unroll
+        for (int it = 0; it < A_IT; ++it) issue_a(a_buf, it, 0);
+        issue_b(b_buf, 0, 0);
+        if constexpr (LA == 2) issue_b(b_buf + B_BYTES, 1, 0);
+        int bcur = 0, bnxt = LA;   // ring slots of step t and of step t + LA
+        for (int ch = 0; ch < cch; ++ch) {
+            const char* acur = a_buf + (ch & 1) * A_BYTES;
+            char* anxt = a_buf + ((ch + 1) & 1) * A_BYTES;
+            const bool more = ch + 1 < cch;
+    #pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (LA == 2 && (tap < 8 || more)) wait_vmcnt<B_IT>();
+                else wait_vmcnt<0>();
+                TV_T(0);
+                __builtin_amdgcn_s_barrier();
+                TV_T(1);
+                const bool b_go = (tap + LA < 9) || more;
+                const int b_koff = ((tap + LA < 9) ? (tap + LA) * p.c_in + ch * BK : (tap + LA - 9) * p.c_in + (ch + 1) * BK) * 2;
+                char* const b_dst = b_buf + bnxt * B_BYTES;
+                TV_T(2);
+    #if TV_HALO_BURST
+                if (tap < A_IT && more) issue_a(anxt, tap, ch + 1);
+                if (b_go) {
+#pragma unroll
+                    for (int it = 0; it < B_IT; ++it) issue_b_piece(b_dst, it, b_koff);
+                }
+                compute(acur, b_buf + bcur * B_BYTES, (tap / 3) * HWD + (tap % 3), [](int) {});
+#else
+                compute(acur, b_buf + bcur * B_BYTES, (tap / 3) * HWD + (tap % 3), [&](int q) {
+                    if (q == 0) {
+                        if (tap < A_IT && more) issue_a(anxt, tap, ch + 1);
+                    } else if (b_go) {
+                        issue_b_piece(b_dst, q - 1, b_koff);
+                    }
+                });
+#endif
+                TV_T(4);
+                bcur = (bcur + 1 == BST) ? 0 : bcur + 1;
+                bnxt = (bnxt + 1 == BST) ? 0 : bnxt + 1;
+            }
+        }
+
     }
+
+    if (TV_SETPRIO) __builtin_amdgcn_s_setprio(0);
+    TV_T(5);
+    __syncthreads();
+    // wave-tile row r -> output pixel: fragment row i = r / 16 is tile row wm*MF + i, r % 16 the column
+    const int pix0 = (b * p.h_out + y0 + wm * MF) * p.w_out + x0;
+    epilogue<WTM, WTN>(p, acc, smem, wave, lane, n0 + wn * WTN, [&](int r) { return pix0 + (r >> 4) * p.w_out + (r & 15); });
+    TV_T(6);
+    TV_PROBE_DUMP(wave, lane);
 }
 
 bool g_use_dma = true;
@@ -417,6 +1001,8 @@ int g_cfg_stages = 0;  // 0 = heuristic, else 2 / 3 / 4
 int g_cfg_bk = 0;      // 0 = largest that divides c_in, else 32 / 64
 int g_cfg_bn = 0;      // 0 = heuristic, 256 = 256-wide N tiles whenever c_out % 256 == 0, 128 = never
 int g_addr_mode = 0;   // 0 = buffer DMA when the tensors are < 2 GiB, 1 = force 64-bit global DMA
+int g_halo_ring = 3;    // weight ring depth of the halo kernel (2 / 3; 3 falls back to 2 where the LDS is too small)
+bool g_use_halo = true;  // 3x3 stride-1 convolutions through conv3x3_halo_kernel when the shape qualifies
 
 constexpr int LDS_MAX = 160 * 1024;
 
@@ -485,6 +1071,58 @@ int launch_mode(IgemmArgs& a, hipStream_t s) {
     return launch_one<128, 32, 4, 1, BK, 2, MODE>(a, s);
 }
 
+template <int BM, int BN, int WGM, int WGN, int BST>
+int launch_halo_one(const IgemmArgs& a, hipStream_t s) {
+    constexpr int NW = WGM * WGN, HP = (BM / 16 + 2) * 18;
+    constexpr int RING = 2 * (((HP * 8 + 63) / 64) * 1024) + BST * BN * 64 * 2;
+    constexpr int EPI = NW * (BM / WGM) * ((BN / WGN) * 2 + 16);
+    constexpr int BYTES = RING > EPI ? RING : EPI;
+    if constexpr (BYTES > LDS_MAX) {
+        return -1;
+    } else {
+        const int tiles_m = a.batch * (a.h_out / (BM / 16)) * (a.w_out / 16);
+        dim3 grid((unsigned)(tiles_m * a.tiles_n)), block(NW * 64);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, BN, WGM, WGN, BST>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WGM, WGN, BST>), grid, block, BYTES, s, a);
+        return 0;
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_halo_ring(const IgemmArgs& a, int ring, hipStream_t s) {
+    if (ring >= 3 && launch_halo_one<BM, BN, WGM, WGN, 3>(a, s) == 0) return 0;
+    return launch_halo_one<BM, BN, WGM, WGN, 2>(a, s);
+}
+
+// same tile heuristic as launch_mode; returns -1 when the shape does not qualify (the generic kernel takes it)
+int launch_halo(IgemmArgs& a, hipStream_t s) {
+    if (!(a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.up_shift == 0 && a.dil_mask == 0 && !a.shuffle)) return -1;
+    if (a.c_in % 64 != 0 || a.N <= 64 || a.x_bytes == 0 || a.w_bytes == 0) return -1;
+    if (a.h_in != a.h_out || a.w_in != a.w_out || a.w_out % 16 != 0 || a.h_out % 8 != 0) return -1;
+    const int N = a.N;
+    const bool h16 = a.h_out % 16 == 0;
+    const long long m256 = (a.M + 255) / 256;
+    if (N % 192 == 0 && N % 128 != 0) {
+        a.tiles_n = N / 192;
+        const int bm = g_cfg_bm ? g_cfg_bm : (m256 * a.tiles_n >= 1024 ? 256 : 128);
+        // weight ring 3 deep only where measured faster (one N tile: res192@256/@128); 2 everywhere else
+        if (bm == 256 && h16) return launch_halo_ring<256, 192, 4, 2>(a, (g_halo_ring == 3 && a.tiles_n == 1) || g_halo_ring == 4 ? 3 : 2, s);
+        return launch_halo_ring<128, 192, 2, 2>(a, g_halo_ring == 4 ? 3 : 2, s);
+    }
+    const bool want256 = g_cfg_bn ? (g_cfg_bn == 256) : (g_cfg_bm == 0 && m256 * (N / 256) >= 512);
+    if (want256 && N % 256 == 0 && h16) {
+        a.tiles_n = N / 256;
+        return launch_halo_ring<256, 256, 2, 4>(a, 2, s);
+    }
+    a.tiles_n = (N + 127) / 128;
+    if (g_cfg_bm == 256 && h16) return launch_halo_ring<256, 128, 4, 2>(a, g_halo_ring == 4 ? 3 : 2, s);
+    return launch_halo_ring<128, 128, 2, 2>(a, g_halo_ring == 4 ? 3 : 2, s);
+}
+
 template <int BK>
 int launch_bk(IgemmArgs& a, hipStream_t s) {
     if (!g_use_dma) return launch_mode<BK, 0>(a, s);
@@ -499,6 +1137,18 @@ extern "C" int tv_set_dma(int on) {   // 0: register staging, 1: LDS-DMA (buffer
     g_addr_mode = (on == 2) ? 1 : 0;
     return 0;
 }
+
+extern "C" int tv_set_igemm_halo(int on) {   // 0: 3x3 stride-1 convolutions through the generic kernel (tests, A/B timing)
+    g_use_halo = on != 0;   // 1: heuristic ring depth, 2: ring 2 everywhere, 4: ring 3 wherever it fits
+    g_halo_ring = (on == 2) ? 2 : (on == 4 ? 4 : 3);
+    return 0;
+}
+
+#ifdef TV_PROBE
+extern "C" int tv_set_igemm_probe(void* dev_buf) {   // 16 blocks x 8 waves x 8 counters (u64), or null
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_probe_dev), &dev_buf, sizeof(void*)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // tuning hook (tools/gemm_sweep.py): 0 restores the built-in heuristic
 extern "C" int tv_set_igemm_config(int bm, int bn, int stages, int bk) {
@@ -578,7 +1228,8 @@ static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, co
     }
     hipStream_t s = (hipStream_t)stream;
     const bool bk64 = (d->c_in % 64 == 0) && g_cfg_bk != 32;
-    int rc = bk64 ? launch_bk<64>(a, s) : launch_bk<32>(a, s);
+    int rc = (g_use_dma && g_use_halo && g_addr_mode != 1 && bk64) ? launch_halo(a, s) : -1;
+    if (rc != 0) rc = bk64 ? launch_bk<64>(a, s) : launch_bk<32>(a, s);
     if (rc != 0) {
         tv_set_error("tv_igemm_nt: no kernel for this configuration");
         return TV_ERR_ARG;

@@ -120,6 +120,8 @@ def load():
             fn.argtypes = args
         lib.tv_set_dma.restype = _I
         lib.tv_set_dma.argtypes = [_I]
+        lib.tv_set_igemm_halo.restype = _I
+        lib.tv_set_igemm_halo.argtypes = [_I]
         lib.tv_set_igemm_config.restype = _I          # tuning hooks, not part of the public ABI
         lib.tv_set_igemm_config.argtypes = [_I, _I, _I, _I]
         lib.tv_set_wgrad_config.restype = _I

@@ -129,6 +129,55 @@ def test_conv_forward_backward(case, dma):
         _lib.load().tv_set_dma(1)
 
 
+# 3x3 stride-1 halo-tile kernel (csrc/igemm_nt.hip: conv3x3_halo_kernel): every tile shape, image borders inside and
+# between tiles, several channel chunks, non-power-of-two grids; (bm, bn) forces the tile through the tuning hook.
+HALO_CASES = [
+    # x shape, Cout, (bm, bn), act, residual
+    ((2, 16, 16, 192), 192, (256, 0), "silu", True),    # 256x192 tile, 3 chunks
+    ((1, 32, 48, 64), 192, (128, 0), None, False),      # 128x192 tile, 8x16 spatial tiles, W = 3 tiles
+    ((2, 16, 32, 256), 256, (0, 256), "gelu", True),    # 256x256 tile, 4 chunks
+    ((3, 24, 16, 128), 256, (0, 0), None, False),       # h % 16 != 0: 128x128 tiles
+    ((1, 48, 32, 64), 128, (256, 128), None, True),     # 256x128 tile
+    ((2, 8, 16, 320), 160, (0, 0), "silu", False),      # N edge in the second 128 tile, 5 chunks, one tile per image
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES, ids=[f"{'x'.join(map(str, c[0]))}-{c[1]}-bm{c[2][0]}bn{c[2][1]}" for c in HALO_CASES])
+def test_conv3x3_halo(case):
+    from transvae.hip import ops, _lib
+    xs, cout, (bm, bn), act, use_res = case
+    lib = _lib.load()
+    x, w, b = _mk("c3s1", xs, (cout, 3, 3), seed=77 + HALO_CASES.index(case))
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    res = r16(gen(xs[0], xs[1], xs[2], cout, seed=5)) if use_res else None
+    rr = res.clone().requires_grad_(True) if use_res else None
+    yref = ref_conv(xr, wr, br, "c3s1", act, rr)
+    gy = r16(gen(*yref.shape, seed=6))
+    yref.backward(gy)
+    outs = {}
+    try:
+        for halo in (1, 0):
+            lib.tv_set_igemm_halo(halo)
+            lib.tv_set_igemm_config(bm, bn, 0, 0)
+            xd = x.to(dev(), BF).requires_grad_(True)
+            wd = w.to(dev()).requires_grad_(True)
+            bd = b.to(dev()).requires_grad_(True)
+            rd = res.to(dev(), BF).requires_grad_(True) if use_res else None
+            y = ops.conv(xd, wd, bd, rd, mode="c3s1", act=act)
+            y.backward(gy.to(dev(), BF))
+            torch.cuda.synchronize()
+            assert rel(y, yref) < 1e-2, f"halo={halo} forward"
+            assert rel(xd.grad, xr.grad) < 1e-2, f"halo={halo} dgrad"
+            assert rel(wd.grad, wr.grad) < 1e-2
+            outs[halo] = (y.float().cpu(), xd.grad.float().cpu())
+        # same math, different summation order: the two kernels agree to about one bf16 rounding step (2^-8)
+        assert rel(outs[1][0], outs[0][0]) < 8e-3
+        assert rel(outs[1][1], outs[0][1]) < 8e-3
+    finally:
+        lib.tv_set_igemm_halo(1)
+        lib.tv_set_igemm_config(0, 0, 0, 0)
+
+
 def test_pack_weight():
     from transvae.hip import ops
     w = gen(40, 9, 72, seed=3)

@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--cfg", default="", help="igemm tuning: bm,bn,stages,bk (0 = heuristic)")
     ap.add_argument("--brief", action="store_true")
+    ap.add_argument("--halo", type=int, default=1, help="3x3 stride-1 halo kernel: 0 off, 1 default, 2 / 3 weight ring depth")
+    ap.add_argument("--only", default="", help="substring filter on the layer name")
     ap.add_argument("--wstages", type=int, default=0, help="wgrad pixels per K-step (0 = heuristic, 32, 64)")
     ap.add_argument("--wblocks", type=int, default=0, help="wgrad split-K block target (0 = heuristic)")
     ap.add_argument("--wwaves", type=int, default=0, help="wgrad waves per block (0 = heuristic, 4)")
@@ -91,9 +93,14 @@ def main():
     if args.wstages or args.wwaves or args.wblocks:
         from transvae.hip import _lib
         _lib.load().tv_set_wgrad_config(args.wstages, args.wwaves, args.wblocks)
+    if args.halo != 1:
+        from transvae.hip import _lib
+        _lib.load().tv_set_igemm_halo(args.halo)
     dev = torch.device("cuda:0")
     rows = []
     for (name, mode, B, H, W, Cin, Cout), count in layer_list(args.variant, args.res, args.mb).items():
+        if args.only and args.only not in name:
+            continue
         if mode == "linear":
             x = torch.randn(B * H * W, Cin, device=dev).to(BF).requires_grad_(True)
             w = (torch.randn(Cout, Cin, device=dev) * Cin ** -0.5).requires_grad_(True)
