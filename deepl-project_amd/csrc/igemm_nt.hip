@@ -10,13 +10,13 @@
 // and their data gradients.
 //
 // Structure: 128- or 256-row tiles, 4 or 8 waves, bf16 v_mfma_f32_16x16x32, operands staged
-// global->LDS with 16-byte LDS-DMA (global_load_lds_dwordx4) into a ring of STAGES buffers.
-// The loads of K-steps t+1 .. t+STAGES-1 are in flight while K-step t is multiplied: one raw
-// s_barrier per K-step and a COUNTED s_waitcnt vmcnt(N) (never 0 in steady state when STAGES > 2),
-// so the DMA spans barriers (cdna_hip_programming.md section 5, "Pipelining across barriers",
-// T3/T4).  The LDS image is lane-linear (DMA constraint); bank conflicts are removed by
-// XOR-swizzling the 16-byte chunk index on the SOURCE address and on the ds_read_b128 address
-// (rule 21).
+// global->LDS with 16-byte LDS-DMA (buffer_load ... lds; global_load_lds for tensors >= 2 GiB) into a ring
+// of STAGES buffers, counted s_waitcnt vmcnt(N) and raw s_barriers so the DMA spans barriers
+// (cdna_hip_programming.md section 5, "Pipelining across barriers", T3/T4).  The main loop is register
+// pipelined: two half-step fragment sets per wave, the barrier between the halves of a K-step (see PIPE2).
+// The LDS image is lane-linear (DMA constraint); bank conflicts are removed by XOR-swizzling the 16-byte
+// chunk index on the SOURCE address and on the ds_read_b128 address (rule 21).
+// 3x3 stride-1 convolutions take conv3x3_halo_kernel below (spatial tiles, halo staged once per chunk).
 //
 // The MFMA is issued as D' = W_frag x A_frag^T so that every lane ends up with 4*NF
 // consecutive output channels of one pixel: bias / activation / residual / store work on

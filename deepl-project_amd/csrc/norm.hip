@@ -4,9 +4,10 @@
 //   RMSNorm / RMSNorm->LayerNorm-hat (token rows) -- blocks.py:179-194 ; attention.py:39-41,71-73
 //
 // GroupNorm statistics need a reduction over all pixels of an image, i.e. across workgroups:
-// every block reduces a slab of pixels to per-channel partial sums (registers -> LDS atomics) and
-// adds them to a [B][C][2] fp32 buffer with one global atomic per channel; groups are folded
-// from channels by the consumer.  The same reduction skeleton serves the backward sums.
+// every block reduces a slab of pixels to per-channel partial sums (registers -> LDS) and writes
+// them to its own row of a partials buffer; a finalize kernel adds the rows in a fixed order into
+// the [B][C][2] fp32 result (no atomics: bit-reproducible); groups are folded from channels by
+// the consumer.  The same reduction skeleton serves the backward sums.
 #include "common.h"
 
 namespace {
