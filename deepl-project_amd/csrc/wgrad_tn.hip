@@ -16,6 +16,10 @@
 // against an all-ones operand in the blocks that own (tap 0, ci tile 0).
 #include "common.h"
 
+#ifndef TV_WGRAD_NO_PIPE
+#define TV_WGRAD_NO_PIPE 0
+#endif
+
 namespace {
 
 struct WgradArgs {
@@ -29,6 +33,7 @@ struct WgradArgs {
     int h_out, w_out, c_out, ldo;
     int kh, kw, stride, pad, up_shift, dil_mask;
     int tiles_ci, chunk_px, hw_shift, w_shift, plain;
+    int xcd_order, base, ny;   // block order: see the kernel
     unsigned x_bytes;   // FAST path: extent of x in bytes
 };
 
@@ -87,10 +92,18 @@ constexpr int wgrad_min_waves() {
 // FAST: stride-1 "same" convolution (or linear layer) on a power-of-two grid with both tensors < 2 GiB: staging by
 // buffer_load...lds with per-thread fixed offsets, the pixel advance in the scalar offset, the tap shift folded into
 // the descriptor base and padding / tails as out-of-range offsets (zeros) -- ~1/3 of the generic path's vector ALU work
-template <int TG, int TX, int BKP, int NWN, bool FAST>
+// register-pipelined main loop where two fragment sets + accumulators + addressing fit the wave's register budget
+template <int TG, int TX, int NWN>
+constexpr bool wgrad_pipe() {
+    const int MF = TG / 2 / 16, NF = TX / NWN / 16;
+    const int est = 2 * (MF + NF) * 4 + MF * NF * 4 + MF * 4 + 40;
+    const int budget = wgrad_min_waves<TG, TX, NWN>() == 3 ? 150 : (NWN == 4 ? 256 : 512);   // (3 waves/SIMD: 168 registers, minus slack)
+    return est <= budget && est <= 216 && !TV_WGRAD_NO_PIPE;
+}
+
+template <int TG, int TX, int BKP, int NWN, bool FAST, int STAGES = 2>
 __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void wgrad_tn_kernel(const WgradArgs p) {
     constexpr int NW = 2 * NWN;                           // waves: 2 over co x NWN over ci
-    constexpr int STAGES = 2;
     constexpr int CG = TG / 8, CX = TX / 8;               // chunks per tile row
     constexpr int G_INSTR = BKP * CG / 64, X_INSTR = BKP * CX / 64;   // 1 KiB pieces per K-step tile
     constexpr int G_IT = (G_INSTR + NW - 1) / NW, X_IT = (X_INSTR + NW - 1) / NW;
@@ -106,7 +119,21 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
     const int wm = wave / NWN, wn = wave % NWN;
 
     const int taps = p.kh * p.kw;
-    int bx = blockIdx.x;
+    // Block order.  All tiles (co, tap, ci) of one pixel chunk read the same gy / x rows; run side by side on ONE XCD they
+    // share them through its L2 (they advance at the same pace; a block that runs ahead misses and falls back in step).
+    // Workgroups go to XCDs round-robin by linear id, so chunk c takes the ids congruent to c mod 8.  Measured on the
+    // dominant 3x3 layer before this: 27.3 GB fetched per launch (FETCH_SIZE) for 3.2 GB of operands, 7.8 TB/s.
+    int bx, chunk_id;
+    if (p.xcd_order) {
+        const int lin = blockIdx.x;
+        const int xcd = lin & 7, j = lin >> 3;
+        bx = j % p.base;
+        chunk_id = (j / p.base) * 8 + xcd;
+        if (chunk_id >= p.ny) return;
+    } else {
+        bx = blockIdx.x;
+        chunk_id = blockIdx.y;
+    }
     const int ci_tile = bx % p.tiles_ci;
     bx /= p.tiles_ci;
     const int tap = bx % taps;
@@ -114,7 +141,7 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
     const int ky = tap / p.kw, kx = tap - ky * p.kw;
     const int co0 = co_tile * TG, ci0 = ci_tile * TX;
 
-    const int p_begin = blockIdx.y * p.chunk_px;
+    const int p_begin = chunk_id * p.chunk_px;
     const int p_end = min(p.M, p_begin + p.chunk_px);
     const int nsteps = (p_end - p_begin + BKP - 1) / BKP;
     if (nsteps <= 0) return;
@@ -291,13 +318,86 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
         }
     };
 
-    // double buffer: the DMA of K-step t+1 is in flight while step t is multiplied
-    stage_issue(0, smem);
-    for (int t = 0; t < nsteps; ++t) {
-        wait_vmcnt<0>();
+    // Register-pipelined loop (same idea as igemm_nt.hip, PIPE2): two 32-pixel fragment sets per wave.  While the MFMAs of
+    // sub-step u run, the transposing reads of sub-step u+1 are in flight -- across the stage boundary too, so the block
+    // barrier sits where every wave has read all of a stage: the stage after it has landed, and the one just left is
+    // refilled.  (The reads are inline asm, invisible to the compiler's waitcnt pass: each set is waited for with an
+    // explicit lgkmcnt(0) BEFORE the next set is issued, when it has had a whole sub-step to land.)
+    constexpr int KH = BKP / 32;
+    constexpr bool PIPE = wgrad_pipe<TG, TX, NWN>();
+    static_assert(STAGES == 2 || PIPE, "the 3-deep ring exists for the pipelined loop only");
+    if constexpr (PIPE) {
+        bf16x4 f0alo[MF], f0ahi[MF], f0blo[NF], f0bhi[NF], f1alo[MF], f1ahi[MF], f1blo[NF], f1bhi[NF];
+        auto read_sub = [&](int u, bf16x4 (&alo)[MF], bf16x4 (&ahi)[MF], bf16x4 (&blo)[NF], bf16x4 (&bhi)[NF]) {
+            const int stage = (u / KH) % STAGES, kk = u % KH;
+            const unsigned sa = smem_addr + stage * STAGE + kk * 32 * (TG * 2);
+            const unsigned sb = smem_addr + stage * STAGE + kk * 32 * (TX * 2);
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                alo[i] = lds_tr16(sa + a_off[0][i]);
+                ahi[i] = lds_tr16(sa + a_off[1][i]);
+            }
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                blo[j] = lds_tr16(sb + b_off[0][j]);
+                bhi[j] = lds_tr16(sb + b_off[1][j]);
+            }
+        };
+        auto mfma_sub = [&](const bf16x4 (&alo)[MF], const bf16x4 (&ahi)[MF], const bf16x4 (&blo)[NF], const bf16x4 (&bhi)[NF]) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const bf16x8 af = join(alo[i], ahi[i]);
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, join(blo[j], bhi[j]), acc[i][j], 0, 0, 0);
+                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[i], 0, 0, 0);
+            }
+        };
+        const int U = nsteps * KH;
+        // sub-step u: wait for its fragments, start the reads of u+1 (after the stage hand-over if u+1 opens a stage), multiply
+        auto sub = [&](int u, auto& calo, auto& cahi, auto& cblo, auto& cbhi, auto& nalo, auto& nahi, auto& nblo, auto& nbhi) {
+            lds_wait_all();
+            if (u + 1 < U) {
+                if ((u + 1) % KH == 0) {
+                    const int s1 = (u + 1) / KH;           // stage about to be read; stage s1-1 is now free
+                    // stage s1 landed; with a 3-deep ring stage s1+1 may stay in flight (parked-wave counters showed the
+                    // 2-deep ring waiting on the DMA for ~half of every wave's lifetime)
+                    if (STAGES == 3 && s1 + 1 < nsteps) wait_vmcnt<G_IT + X_IT>();
+                    else wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    if (s1 + STAGES - 1 < nsteps) stage_issue(s1 + STAGES - 1, smem + ((s1 + STAGES - 1) % STAGES) * STAGE);
+                }
+                read_sub(u + 1, nalo, nahi, nblo, nbhi);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_sub(calo, cahi, cblo, cbhi);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        static_assert(STAGES == 2 || (G_INSTR % NW == 0 && X_INSTR % NW == 0), "counted waits need the same DMA count in every wave");
+#pragma unroll
+        for (int st = 0; st < STAGES; ++st)
+            if (st < nsteps) stage_issue(st, smem + st * STAGE);
+        constexpr bool UNIFORM = G_INSTR % NW == 0 && X_INSTR % NW == 0;   // else: waves with fewer pieces must not under-wait
+        if (UNIFORM && STAGES == 3 && nsteps >= 3) wait_vmcnt<2 * (G_IT + X_IT)>();
+        else if (UNIFORM && nsteps >= 2) wait_vmcnt<G_IT + X_IT>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (t + 1 < nsteps) stage_issue(t + 1, smem + ((t + 1) & 1) * STAGE);
-        compute(t & 1);
+        read_sub(0, f0alo, f0ahi, f0blo, f0bhi);
+        int u = 0;
+        for (; u + 1 < U; u += 2) {
+            sub(u, f0alo, f0ahi, f0blo, f0bhi, f1alo, f1ahi, f1blo, f1bhi);
+            sub(u + 1, f1alo, f1ahi, f1blo, f1bhi, f0alo, f0ahi, f0blo, f0bhi);
+        }
+        if (u < U) sub(u, f0alo, f0ahi, f0blo, f0bhi, f1alo, f1ahi, f1blo, f1bhi);
+    } else {
+        // double buffer: the DMA of K-step t+1 is in flight while step t is multiplied
+        stage_issue(0, smem);
+        for (int t = 0; t < nsteps; ++t) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < nsteps) stage_issue(t + 1, smem + ((t + 1) & 1) * STAGE);
+            compute(t & 1);
+        }
     }
 
     // ---- fp32 atomics into dw[co][tap][ci]; D layout: row = (lane>>4)*4+reg (co), col = lane&15 (ci)
@@ -328,23 +428,34 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
 int g_wgrad_bkp = 0;     // 0 = heuristic (64), else 32 / 64 pixels per K-step
 int g_wgrad_blocks = 0;  // 0 = heuristic: target number of blocks for the split-K choice
 int g_wgrad_tile256 = 0; // 0 = heuristic (linear layers only), 1 = always when both channel counts are multiples of 256, 2 = never
+int g_wgrad_xcd = 1;     // 1 = tiles of one pixel chunk share an XCD (block order in the kernel)
 int g_wgrad_generic = 0; // 1 = never use the FAST staging path (A/B)
 int g_wgrad_waves = 0;   // 0 = heuristic (8 waves for the 192-wide co tile), 4 / 8 = force
 
-template <int TG, int TX, int BKP, int NWN, bool FAST>
-int launch_f(const WgradArgs& a, dim3 grid, hipStream_t s) {
-    constexpr int BYTES = 2 * BKP * (TG + TX) * 2;
-    if constexpr (BYTES > 160 * 1024 || (TX / NWN) % 16 != 0) {
+template <int TG, int TX, int BKP, int NWN, bool FAST, int STAGES>
+int launch_st(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int BYTES = STAGES * BKP * (TG + TX) * 2;
+    constexpr int NW = 2 * NWN;
+    constexpr bool uniform = (BKP * (TG / 8) / 64) % NW == 0 && (BKP * (TX / 8) / 64) % NW == 0;
+    if constexpr (BYTES > 160 * 1024 || (TX / NWN) % 16 != 0 || (STAGES == 3 && (!uniform || NWN != 4 || !wgrad_pipe<TG, TX, NWN>()))) {
         return -1;
     } else {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<TG, TX, BKP, NWN, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+            (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<TG, TX, BKP, NWN, FAST, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
             attr_done = true;
         }
-        hipLaunchKernelGGL((wgrad_tn_kernel<TG, TX, BKP, NWN, FAST>), grid, dim3(128 * NWN), BYTES, s, a);
+        hipLaunchKernelGGL((wgrad_tn_kernel<TG, TX, BKP, NWN, FAST, STAGES>), grid, dim3(128 * NWN), BYTES, s, a);
         return 0;
     }
+}
+
+int g_wgrad_stages = 0;  // 0 = heuristic (3 where an 8-wave tile leaves the LDS room), 2 / 3 = force
+
+template <int TG, int TX, int BKP, int NWN, bool FAST>
+int launch_f(const WgradArgs& a, dim3 grid, hipStream_t s) {
+    if (g_wgrad_stages != 2 && launch_st<TG, TX, BKP, NWN, FAST, 3>(a, grid, s) == 0) return 0;
+    return launch_st<TG, TX, BKP, NWN, FAST, 2>(a, grid, s);
 }
 
 template <int TG, int TX, int BKP, int NWN>
@@ -368,15 +479,28 @@ int launch(const WgradArgs& a0, hipStream_t s) {
     const double t_px = 2.0 * TG * TX * slots / 750e12;                // seconds per pixel for one resident block
     const double tile_bytes = 4.0 * TG * TX;
     long long split = 1;
+    bool xcd = false;
     if (g_wgrad_blocks) {
         split = (g_wgrad_blocks + base - 1) / base;
+        xcd = g_wgrad_xcd && a.kh * a.kw > 1;
     } else {
         double best = 1e30;
         const long long smax = a.M / 512 > 0 ? a.M / 512 : 1;
         for (long long sp = 1; sp <= smax && sp <= 4096; ++sp) {
             const double rounds = (double)((long long)((base * sp + slots - 1) / slots));
             const double t = rounds * ((double)a.M / sp) * t_px + (sp > 1 ? base * sp * tile_bytes / 1.3e12 : 0.0);
-            if (t < best) { best = t; split = sp; }
+            if (t < best) { best = t; split = sp; xcd = false; }
+        }
+        // XCD-grouped order (multi-tap layers: every tap re-reads the same rows; one pixel chunk per XCD at a time shares
+        // them through that L2, measured +35 % per block on the 192-channel layers): chunk c runs on XCD c % 8, so the load
+        // is per XCD: base * ceil(split / 8) blocks on 32 * per_cu slots.
+        const double xslots = 32.0 * per_cu;
+        if (g_wgrad_xcd && a.kh * a.kw > 1 && base <= xslots) {   // (a chunk's tiles must be co-resident on the XCD; else measured slower)
+            for (long long sp = 8; sp <= smax && sp <= 4096; sp += 8) {
+                const double rounds = (double)((long long)((base * (sp / 8) + xslots - 1) / xslots));
+                const double t = rounds * ((double)a.M / sp) * (t_px * 0.75) + base * sp * tile_bytes / 1.3e12;
+                if (t < best) { best = t; split = sp; xcd = true; }
+            }
         }
     }
     long long chunk = (a.M + split - 1) / split;
@@ -385,7 +509,11 @@ int launch(const WgradArgs& a0, hipStream_t s) {
     a.chunk_px = (int)chunk;
     const int ny = (int)((a.M + chunk - 1) / chunk);
     a.plain = (ny == 1) ? 1 : 0;
+    a.base = (int)base;
+    a.ny = ny;
+    a.xcd_order = (ny > 1 && xcd) ? 1 : 0;
     dim3 grid((unsigned)base, (unsigned)ny);
+    if (a.xcd_order) grid = dim3((unsigned)(8 * base * ((ny + 7) / 8)), 1);
     auto log2_exact = [](int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; };
     a.w_shift = log2_exact(a.w_out);
     a.hw_shift = log2_exact(a.h_out * a.w_out);
@@ -408,6 +536,12 @@ int launch(const WgradArgs& a0, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int tv_set_wgrad_stages(int stages) {   // 0 = heuristic, 2 / 3; +10: plain (chunk-major) block order
+    g_wgrad_xcd = stages >= 10 ? 0 : 1;
+    g_wgrad_stages = stages % 10;
+    return 0;
+}
 
 extern "C" int tv_set_wgrad_config(int bkp, int waves, int blocks) {
     g_wgrad_generic = (blocks == -1) ? 1 : 0;
@@ -445,6 +579,7 @@ extern "C" int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy,
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
     a.up_shift = d->up_shift; a.dil_mask = d->dil_mask;
     a.tiles_ci = 1; a.chunk_px = 0; a.hw_shift = -1; a.w_shift = -1; a.plain = 0; a.x_bytes = 0;
+    a.xcd_order = 0; a.base = 1; a.ny = 1;
     hipStream_t s = (hipStream_t)stream;
     // 256x256 tiles (8 waves, 128x64 per wave): +5..20 % on linear layers, -9 % on 9-tap convolutions (gemm_sweep, mb 64)
     if ((g_wgrad_tile256 == 1 || (g_wgrad_tile256 == 0 && d->kh * d->kw == 1)) && d->c_out % 256 == 0 && d->c_in % 256 == 0) {

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--cfg", default="", help="igemm tuning: bm,bn,stages,bk (0 = heuristic)")
     ap.add_argument("--brief", action="store_true")
     ap.add_argument("--halo", type=int, default=1, help="3x3 stride-1 halo kernel: 0 off, 1 default, 2 / 3 weight ring depth")
+    ap.add_argument("--wring", type=int, default=0, help="wgrad LDS ring depth (0 = heuristic, 2, 3)")
     ap.add_argument("--only", default="", help="substring filter on the layer name")
     ap.add_argument("--wstages", type=int, default=0, help="wgrad pixels per K-step (0 = heuristic, 32, 64)")
     ap.add_argument("--wblocks", type=int, default=0, help="wgrad split-K block target (0 = heuristic)")
@@ -96,6 +97,9 @@ def main():
     if args.halo != 1:
         from transvae.hip import _lib
         _lib.load().tv_set_igemm_halo(args.halo)
+    if args.wring:
+        from transvae.hip import _lib
+        _lib.load().tv_set_wgrad_stages(args.wring)
     dev = torch.device("cuda:0")
     rows = []
     for (name, mode, B, H, W, Cin, Cout), count in layer_list(args.variant, args.res, args.mb).items():
