@@ -40,7 +40,7 @@ struct IgemmArgs {
     int batch, h_in, w_in, c_in, ldx;
     int h_out, w_out, ldo;
     int kh, kw, stride, pad, up_shift, dil_mask;
-    int tiles_n;
+    int tiles_n, tiles_m, xcd_order;
     int shuffle;
     int act;
     int aux_act;
@@ -62,6 +62,9 @@ struct IgemmArgs {
 #endif
 #ifndef TV_GENERIC_BURST
 #define TV_GENERIC_BURST 1    // same for the generic 256x256 tile (A/B on the 768-channel linear layers: +2-5 %)
+#endif
+#ifndef TV_RD_THREAD
+#define TV_RD_THREAD 0
 #endif
 #ifndef TV_SETPRIO
 #define TV_SETPRIO 1           // waves 4-7 (the arbitration losers on every SIMD) run at priority 1
@@ -229,8 +232,20 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    const int tile_n = blockIdx.x % p.tiles_n;
-    const int tile_m = blockIdx.x / p.tiles_n;
+    // Block order.  The tiles_n blocks of one row tile read the same activation rows; on ONE XCD they share them through
+    // its L2 instead of fetching them tiles_n times from HBM / Infinity Cache (a K = 384, N = 1536 linear layer moved
+    // 2.4 GB in 0.47 ms that way: memory bound).  Workgroups go to XCDs round-robin by linear id, so row tile m takes
+    // the ids congruent to m mod 8, its column tiles consecutive within that XCD's sequence.
+    int tile_n, tile_m;
+    if (p.xcd_order) {
+        const int lin = blockIdx.x, j = lin >> 3;
+        tile_n = j % p.tiles_n;
+        tile_m = (j / p.tiles_n) * 8 + (lin & 7);
+        if (tile_m >= p.tiles_m) return;
+    } else {
+        tile_n = blockIdx.x % p.tiles_n;
+        tile_m = blockIdx.x / p.tiles_n;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-thread staging bookkeeping ------------------------------------------------
@@ -672,7 +687,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
     constexpr int BK = 64, NW = WGM * WGN, TW = 16, TH = BM / TW, HWD = TW + 2, HP = (TH + 2) * HWD;
     constexpr int A_PIECES = (HP * 8 + 63) / 64;             // 1 KiB DMA pieces per halo chunk (8 pixels each)
     constexpr int WTM = BM / WGM, WTN = BN / WGN, MF = WTM / 16, NF = WTN / 16;
-    constexpr bool PIPE_ALL = (MF + NF) * 4 * (BK / 32) <= 80;
+    constexpr bool PIPE_ALL = (MF + NF) * 4 * (BK / 32) <= (NW == 4 && BM == 256 ? 128 : 80);   // (one wave per SIMD owns 512 registers)
     // Loader waves.  Waves w and w+4 of an 8-wave block share a SIMD and run in lockstep between barriers; a DMA issued by
     // all eight at the same point of the MFMA stream queues ~120 cycles at the address pipe (64 B/clk per CU) and stalls
     // BOTH waves of every SIMD.  In the pipelined loop only waves 0 .. NWL-1 issue DMAs: while one of them waits at the
@@ -693,8 +708,20 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    const int tile_n = blockIdx.x % p.tiles_n;
-    const int tile_m = blockIdx.x / p.tiles_n;
+    // Block order.  The tiles_n blocks of one row tile read the same activation rows; on ONE XCD they share them through
+    // its L2 instead of fetching them tiles_n times from HBM / Infinity Cache (a K = 384, N = 1536 linear layer moved
+    // 2.4 GB in 0.47 ms that way: memory bound).  Workgroups go to XCDs round-robin by linear id, so row tile m takes
+    // the ids congruent to m mod 8, its column tiles consecutive within that XCD's sequence.
+    int tile_n, tile_m;
+    if (p.xcd_order) {
+        const int lin = blockIdx.x, j = lin >> 3;
+        tile_n = j % p.tiles_n;
+        tile_m = (j / p.tiles_n) * 8 + (lin & 7);
+        if (tile_m >= p.tiles_m) return;
+    } else {
+        tile_n = blockIdx.x % p.tiles_n;
+        tile_m = blockIdx.x / p.tiles_n;
+    }
     const int n0 = tile_n * BN;
     const int tiles_x = p.w_out / TW, tiles_y = p.h_out / TH;
     const int b = tile_m / (tiles_x * tiles_y);
@@ -738,10 +765,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
         for (int it = 0; it < B_IT; ++it) b_voff_r[it] = b_voff_of(it * NWL + wave);
     }
     auto issue_a = [&](char* dst, int it, int ch) {   // piece `it` of this (loader) wave, channel chunk ch
+#ifdef TV_ABL_NO_DMA
+        return;
+#endif
         const int j = it * NWL + wave;
         if (j < A_PIECES) buffer_load_lds16(p.x, p.x_bytes, dst + j * 1024, VOFF_REGS ? a_voff_r[VOFF_REGS ? it : 0] : a_voff_of(j), ch * (BK * 2));
     };
     auto issue_b_piece = [&](char* dst, int it, int koff) {
+#ifdef TV_ABL_NO_DMA
+        return;
+#endif
         buffer_load_lds16(p.w, p.w_bytes, dst + (it * NWL + wave) * 1024, VOFF_REGS ? b_voff_r[VOFF_REGS ? it : 0] : b_voff_of(it * NWL + wave), koff);
     };
     auto issue_b = [&](char* dst, int tap, int ch) {
@@ -846,25 +879,65 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
         constexpr int HMF = MF * NF, NIS = B_IT + A_PT, HGAP = HMF / NIS;
         static_assert(HGAP >= 1, "more DMA pieces than MFMAs in a half-step");
         bf16x8 f0a[MF], f0b[NF], f1a[MF], f1b[NF];
+#ifdef TV_ABL_CHEAP_ADDR
+        const int abl_a_off = (hp_base & ~7) * (BK * 2) + fi * (BK * 2) + ((fq ^ (fi & 7)) << 4);   // conflict-free, tap-invariant
+#endif
+#ifdef TV_ABL_NO_LDSREAD
+        for (int i = 0; i < MF; ++i) { f0a[i] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; f1a[i] = f0a[i]; asm volatile("" : "+v"(f0a[i]), "+v"(f1a[i])); }
+        for (int j = 0; j < NF; ++j) { f0b[j] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; f1b[j] = f0b[j]; asm volatile("" : "+v"(f0b[j]), "+v"(f1b[j])); }
+#endif
         auto read_half = [&](const char* abase, const char* bbase, int toff, int kk, bf16x8 (&fa)[MF], bf16x8 (&fb)[NF]) {
+#ifdef TV_ABL_NO_LDSREAD
+            return;
+#endif
             int hpb = hp_base;
             asm volatile("" : "+v"(hpb));   // pin the address arithmetic to this tap (see compute)
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
+#ifdef TV_ABL_CHEAP_ADDR
+                fa[i] = *(const bf16x8*)(abase + abl_a_off + i * HWD * (BK * 2) + kk * 64);
+#else
                 const int hp = hpb + i * HWD + toff;
                 fa[i] = *(const bf16x8*)(abase + hp * (BK * 2) + (((kk * 4 + fq) ^ (hp & 7)) << 4));
+#endif
             }
             const int coff = ((kk * 4 + fq) ^ sw) * 16;
 #pragma unroll
             for (int j = 0; j < NF; ++j) fb[j] = *(const bf16x8*)(bbase + b_row_off + j * 4 * (BK * 2) + coff);
         };
-        auto mfma_half = [&](const bf16x8 (&fa)[MF], const bf16x8 (&fb)[NF], auto issue) {
+        // One wave per SIMD (4-wave 256-row tile) has no partner to cover a block of fragment reads: there the reads of the
+        // next half-step are threaded between the MFMAs as well (RD_THREAD), in the order the MFMAs will want them.
+        constexpr bool RD_THREAD = (NW == 4 && BM == 256) || TV_RD_THREAD;
+        constexpr int NRD = MF + NF, RGAP = HMF / NRD > 0 ? HMF / NRD : 1;
+        auto read_piece = [&](const char* abase, const char* bbase, int hpb, int toff, int kk, bf16x8 (&fa)[MF], bf16x8 (&fb)[NF], int k) {
+#ifdef TV_ABL_NO_LDSREAD
+            return;
+#endif
+            if (k >= 1 && k <= NF) {
+                const int j = k - 1;
+                fb[j] = *(const bf16x8*)(bbase + b_row_off + j * 4 * (BK * 2) + ((kk * 4 + fq) ^ sw) * 16);
+            } else {
+                const int i = k == 0 ? 0 : k - NF;
+#ifdef TV_ABL_CHEAP_ADDR
+                fa[i] = *(const bf16x8*)(abase + abl_a_off + i * HWD * (BK * 2) + kk * 64);
+#else
+                const int hp = hpb + i * HWD + toff;
+                fa[i] = *(const bf16x8*)(abase + hp * (BK * 2) + (((kk * 4 + fq) ^ (hp & 7)) << 4));
+#endif
+            }
+        };
+        auto mfma_half = [&](const bf16x8 (&fa)[MF], const bf16x8 (&fb)[NF], auto issue, auto rd) {
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
                     const int idx = i * NF + j;
+                    if (RD_THREAD && idx % RGAP == 0 && idx / RGAP < NRD) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        rd(idx / RGAP);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (idx % HGAP == HGAP - 1 && idx / HGAP < NIS) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue(idx / HGAP);
@@ -893,24 +966,36 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                     constexpr int tap = decltype(tap_c)::value;
                     char* const bslot = b_buf + bcur * B_BYTES;
                     const char* const bnext = b_buf + ((bcur + 1 == BST) ? 0 : bcur + 1) * B_BYTES;
-                    read_half(acur, bslot, (tap / 3) * HWD + (tap % 3), 1, f1a, f1b);
+                    constexpr int toff = (tap / 3) * HWD + (tap % 3), toff_n = tap < 8 ? ((tap + 1) / 3) * HWD + ((tap + 1) % 3) : 0;
+                    int hpb = hp_base;
+                    if constexpr (RD_THREAD) asm volatile("" : "+v"(hpb));   // pin the address arithmetic to this tap (see compute)
+                    if constexpr (!RD_THREAD) read_half(acur, bslot, toff, 1, f1a, f1b);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma_half(f0a, f0b, [](int) {});
+                    mfma_half(f0a, f0b, [](int) {}, [&](int k) { read_piece(acur, bslot, hpb, toff, 1, f1a, f1b, k); });
                     __builtin_amdgcn_sched_barrier(0);
                     TV_T(3);
-                    if (tap < 8 || more) {
+                    const bool go_on = tap < 8 || more;
+                    if (go_on) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of step t are done: its slab slot may be refilled
                         if constexpr (LOADER) {
                             if (more) wait_vmcnt<(BST == 3 ? nsure(tap - 2) + B_IT : 0) + nsure(tap - 1)>();
                             else wait_vmcnt<(BST == 3 && tap <= 6) ? B_IT : 0>();
                         }
                         TV_T(0);
+#ifndef TV_ABL_NO_BARRIER
                         __builtin_amdgcn_s_barrier();
+#endif
                         TV_T(1);
-                        if (tap < 8) read_half(acur, bnext, ((tap + 1) / 3) * HWD + ((tap + 1) % 3), 0, f0a, f0b);
-                        else read_half(anxt, bnext, 0, 0, f0a, f0b);
+                        if constexpr (!RD_THREAD) {
+                            if (tap < 8) read_half(acur, bnext, toff_n, 0, f0a, f0b);
+                            else read_half(anxt, bnext, 0, 0, f0a, f0b);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    const char* const a_n = tap < 8 ? acur : (const char*)anxt;
+                    auto rd_next = [&](int k) {
+                        if (go_on) read_piece(a_n, bnext, hpb, toff_n, 0, f0a, f0b, k);
+                    };
                     if constexpr (LOADER) {
                         const bool b_go = (tap + BST < 9) || more;
                         const int b_koff = ((tap + BST < 9) ? (tap + BST) * p.c_in + ch * BK : (tap + BST - 9) * p.c_in + (ch + 1) * BK) * 2;
@@ -920,9 +1005,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                             } else if (tap < ATAPS && tap * A_PT + (q - B_IT) < A_IT && more) {
                                 issue_a(anxt, tap * A_PT + (q - B_IT), ch + 1);
                             }
-                        });
+                        }, rd_next);
                     } else {
-                        mfma_half(f1a, f1b, [](int) {});
+                        mfma_half(f1a, f1b, [](int) {}, rd_next);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     TV_T(4);
@@ -1002,20 +1087,25 @@ int g_cfg_bk = 0;      // 0 = largest that divides c_in, else 32 / 64
 int g_cfg_bn = 0;      // 0 = heuristic, 256 = 256-wide N tiles whenever c_out % 256 == 0, 128 = never
 int g_addr_mode = 0;   // 0 = buffer DMA when the tensors are < 2 GiB, 1 = force 64-bit global DMA
 int g_halo_ring = 3;    // weight ring depth of the halo kernel (2 / 3; 3 falls back to 2 where the LDS is too small)
+bool g_halo_w4 = false;   // experiment: 256x192 halo tile with 4 waves (one per SIMD, 128x96 wave tiles)
+bool g_xcd_order = true;  // column tiles of a row tile on one XCD (block order in the kernels)
 bool g_use_halo = true;  // 3x3 stride-1 convolutions through conv3x3_halo_kernel when the shape qualifies
 
 constexpr int LDS_MAX = 160 * 1024;
 
 template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE>
-int launch_one(const IgemmArgs& a, hipStream_t s) {
+int launch_one(const IgemmArgs& a_in, hipStream_t s) {
     constexpr int RING = STAGES * (BM + BN) * BK * 2 + (STAGES > 2 ? 1024 : 0);  // + dummy-DMA scratch slot
     constexpr int EPI = (WGM * WGN) * (BM / WGM) * ((BN / WGN) * 2 + 16);         // parked output tile (epilogue)
     constexpr int BYTES = RING > EPI ? RING : EPI;
     if constexpr (BYTES > LDS_MAX) {
         return -1;
     } else {
-        const int tiles_m = (a.M + BM - 1) / BM;
-        dim3 grid((unsigned)(tiles_m * a.tiles_n)), block(WGM * WGN * 64);
+        const int tiles_m = (a_in.M + BM - 1) / BM;
+        IgemmArgs a = a_in;
+        a.tiles_m = tiles_m;
+        a.xcd_order = (g_xcd_order && a.tiles_n > 1) ? 1 : 0;
+        dim3 grid((unsigned)(a.xcd_order ? 8 * a.tiles_n * ((tiles_m + 7) / 8) : tiles_m * a.tiles_n)), block(WGM * WGN * 64);
         static bool attr_done = false;
         if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in
             (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE>,
@@ -1072,7 +1162,7 @@ int launch_mode(IgemmArgs& a, hipStream_t s) {
 }
 
 template <int BM, int BN, int WGM, int WGN, int BST>
-int launch_halo_one(const IgemmArgs& a, hipStream_t s) {
+int launch_halo_one(const IgemmArgs& a_in, hipStream_t s) {
     constexpr int NW = WGM * WGN, HP = (BM / 16 + 2) * 18;
     constexpr int RING = 2 * (((HP * 8 + 63) / 64) * 1024) + BST * BN * 64 * 2;
     constexpr int EPI = NW * (BM / WGM) * ((BN / WGN) * 2 + 16);
@@ -1080,8 +1170,11 @@ int launch_halo_one(const IgemmArgs& a, hipStream_t s) {
     if constexpr (BYTES > LDS_MAX) {
         return -1;
     } else {
-        const int tiles_m = a.batch * (a.h_out / (BM / 16)) * (a.w_out / 16);
-        dim3 grid((unsigned)(tiles_m * a.tiles_n)), block(NW * 64);
+        const int tiles_m = a_in.batch * (a_in.h_out / (BM / 16)) * (a_in.w_out / 16);
+        IgemmArgs a = a_in;
+        a.tiles_m = tiles_m;
+        a.xcd_order = (g_xcd_order && a.tiles_n > 1) ? 1 : 0;
+        dim3 grid((unsigned)(a.xcd_order ? 8 * a.tiles_n * ((tiles_m + 7) / 8) : tiles_m * a.tiles_n)), block(NW * 64);
         static bool attr_done = false;
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, BN, WGM, WGN, BST>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
@@ -1110,6 +1203,7 @@ int launch_halo(IgemmArgs& a, hipStream_t s) {
         a.tiles_n = N / 192;
         const int bm = g_cfg_bm ? g_cfg_bm : (m256 * a.tiles_n >= 1024 ? 256 : 128);
         // weight ring 3 deep only where measured faster (one N tile: res192@256/@128); 2 everywhere else
+        if (bm == 256 && h16 && g_halo_w4) return launch_halo_ring<256, 192, 2, 2>(a, (g_halo_ring == 3 && a.tiles_n == 1) || g_halo_ring == 4 ? 3 : 2, s);
         if (bm == 256 && h16) return launch_halo_ring<256, 192, 4, 2>(a, (g_halo_ring == 3 && a.tiles_n == 1) || g_halo_ring == 4 ? 3 : 2, s);
         return launch_halo_ring<128, 192, 2, 2>(a, g_halo_ring == 4 ? 3 : 2, s);
     }
@@ -1139,6 +1233,10 @@ extern "C" int tv_set_dma(int on) {   // 0: register staging, 1: LDS-DMA (buffer
 }
 
 extern "C" int tv_set_igemm_halo(int on) {   // 0: 3x3 stride-1 convolutions through the generic kernel (tests, A/B timing)
+    g_halo_w4 = on >= 100;  // +100: 4-wave 256x192 halo tile
+    on %= 100;
+    g_xcd_order = on < 10;  // +10: plain (row-tile-major) block order, for A/B timing
+    on %= 10;
     g_use_halo = on != 0;   // 1: heuristic ring depth, 2: ring 2 everywhere, 4: ring 3 wherever it fits
     g_halo_ring = (on == 2) ? 2 : (on == 4 ? 4 : 3);
     return 0;
