@@ -482,7 +482,7 @@ int launch(const WgradArgs& a0, hipStream_t s) {
     bool xcd = false;
     if (g_wgrad_blocks) {
         split = (g_wgrad_blocks + base - 1) / base;
-        xcd = g_wgrad_xcd && a.kh * a.kw > 1;
+        xcd = g_wgrad_xcd != 0;
     } else {
         double best = 1e30;
         const long long smax = a.M / 512 > 0 ? a.M / 512 : 1;
@@ -491,11 +491,11 @@ int launch(const WgradArgs& a0, hipStream_t s) {
             const double t = rounds * ((double)a.M / sp) * t_px + (sp > 1 ? base * sp * tile_bytes / 1.3e12 : 0.0);
             if (t < best) { best = t; split = sp; xcd = false; }
         }
-        // XCD-grouped order (multi-tap layers: every tap re-reads the same rows; one pixel chunk per XCD at a time shares
-        // them through that L2, measured +35 % per block on the 192-channel layers): chunk c runs on XCD c % 8, so the load
+        // XCD-grouped order (every tile of a pixel chunk re-reads the same rows; one chunk per XCD at a time shares them
+        // through that L2: measured +35 % per block on the 192-channel 3x3 layers, +15-45 % on the 384-channel linear ones): chunk c runs on XCD c % 8, so the load
         // is per XCD: base * ceil(split / 8) blocks on 32 * per_cu slots.
         const double xslots = 32.0 * per_cu;
-        if (g_wgrad_xcd && a.kh * a.kw > 1 && base <= xslots) {   // (a chunk's tiles must be co-resident on the XCD; else measured slower)
+        if (g_wgrad_xcd && base <= xslots) {   // (a chunk's tiles must be co-resident on the XCD; else measured slower)
             for (long long sp = 8; sp <= smax && sp <= 4096; sp += 8) {
                 const double rounds = (double)((long long)((base * (sp / 8) + xslots - 1) / xslots));
                 const double t = rounds * ((double)a.M / sp) * (t_px * 0.75) + base * sp * tile_bytes / 1.3e12;
