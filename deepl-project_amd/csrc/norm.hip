@@ -109,19 +109,28 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const bf16* __r
             mr[((size_t)b * G + g) * 2] = s_mean[g];
             mr[((size_t)b * G + g) * 2 + 1] = s_rstd[g];
         }
+    // one 16-byte channel chunk per thread for the whole slab: scale / shift in registers
     const int nch = C >> 3;
-    const long long total = (long long)min(hw - blockIdx.x * GN_PIX_PER_BLOCK, GN_PIX_PER_BLOCK) * nch;
-    const size_t off0 = ((size_t)b * hw + (size_t)blockIdx.x * GN_PIX_PER_BLOCK) * C;
-    for (long long i = threadIdx.x; i < total; i += GN_THREADS) {
-        const int chunk = (int)(i % nch);
-        const bf16x8 v = *(const bf16x8*)(x + off0 + i * 8);
+    const int rows = GN_THREADS / nch;
+    const int chunk = threadIdx.x % nch, prow = threadIdx.x / nch;
+    if (prow >= rows) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = s_scale[chunk * 8 + e];
+        sh[e] = s_shift[chunk * 8 + e];
+    }
+    const int p0 = blockIdx.x * GN_PIX_PER_BLOCK;
+    const int p1 = min(hw, p0 + GN_PIX_PER_BLOCK);
+    const size_t img = (size_t)b * hw;
+#pragma unroll 2
+    for (int px = p0 + prow; px < p1; px += rows) {
+        const size_t off = (img + px) * C + chunk * 8;
+        const bf16x8 v = *(const bf16x8*)(x + off);
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = chunk * 8 + e;
-            o[e] = (bf16)tv_silu(fmaf((float)v[e], s_scale[c], s_shift[c]));
-        }
-        *(bf16x8*)(y + off0 + i * 8) = o;
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)tv_silu(fmaf((float)v[e], sc[e], sh[e]));
+        *(bf16x8*)(y + off) = o;
     }
 }
 
@@ -222,26 +231,44 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_apply_kernel(const bf1
         }
     }
     __syncthreads();
+    // Each thread keeps one 16-byte channel chunk for the whole slab (the mapping of gn_stats), so the per-channel terms
+    // live in registers:  h = x*A + B,  dx = dh*A - x*Cc + D  with A = rstd*gamma, B = beta - mean*A,
+    // Cc = rstd^2 * S2_g/n, D = mean*Cc - rstd * S1_g/n.  (Was: six LDS reads per element and a 64-bit modulo per vector;
+    // 4.5 TB/s of the ~6.3 TB/s the other norm kernels reach.)
     const int nch = C >> 3;
-    const long long total = (long long)min(hw - blockIdx.x * GN_PIX_PER_BLOCK, GN_PIX_PER_BLOCK) * nch;
-    const size_t off0 = ((size_t)b * hw + (size_t)blockIdx.x * GN_PIX_PER_BLOCK) * C;
-    for (long long i = threadIdx.x; i < total; i += GN_THREADS) {
-        const int chunk = (int)(i % nch);
-        const bf16x8 xv = *(const bf16x8*)(x + off0 + i * 8);
-        const bf16x8 gv = *(const bf16x8*)(dy + off0 + i * 8);
+    const int rows = GN_THREADS / nch;
+    const int chunk = threadIdx.x % nch, prow = threadIdx.x / nch;
+    if (prow >= rows) return;
+    float cA[8], cB[8], cC[8], cD[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = chunk * 8 + e;
+        const float rs = s_rstd[c], mu = s_mean[c];
+        cA[e] = rs * s_ga[c];
+        cB[e] = s_be[c] - mu * cA[e];
+        cC[e] = rs * rs * s_m2[c];
+        cD[e] = mu * cC[e] - rs * s_m1[c];
+    }
+    const int p0 = blockIdx.x * GN_PIX_PER_BLOCK;
+    const int p1 = min(hw, p0 + GN_PIX_PER_BLOCK);
+    const size_t img = (size_t)b * hw;
+#pragma unroll 2
+    for (int px = p0 + prow; px < p1; px += rows) {
+        const size_t off = (img + px) * C + chunk * 8;
+        const bf16x8 xv = *(const bf16x8*)(x + off);
+        const bf16x8 gv = *(const bf16x8*)(dy + off);
         bf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (dres) rv = *(const bf16x8*)(dres + off0 + i * 8);
+        if (dres) rv = *(const bf16x8*)(dres + off);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int c = chunk * 8 + e;
-            const float xh = ((float)xv[e] - s_mean[c]) * s_rstd[c];
-            const float h = fmaf(xh, s_ga[c], s_be[c]);
+            const float xf = (float)xv[e];
+            const float h = fmaf(xf, cA[e], cB[e]);
             const float dh = (float)gv[e] * tv_silu_grad(h);
-            const float d = s_rstd[c] * (dh * s_ga[c] - s_m1[c] - xh * s_m2[c]);
+            const float d = fmaf(dh, cA[e], fmaf(-xf, cC[e], cD[e]));
             o[e] = (bf16)(d + (float)rv[e]);
         }
-        *(bf16x8*)(dx + off0 + i * 8) = o;
+        *(bf16x8*)(dx + off) = o;
     }
 }
 
