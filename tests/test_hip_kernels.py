@@ -178,6 +178,52 @@ def test_conv3x3_halo(case):
         lib.tv_set_igemm_config(0, 0, 0, 0)
 
 
+# Tuning variants that the heuristics only pick at full size: forced here on small problems so that their indexing is
+# covered -- XCD-grouped block orders with tile counts that are not multiples of 8, the 3-deep wgrad ring, the 4-wave
+# 256x192 halo tile, the 3-deep halo weight ring on a multi-chunk problem.
+VARIANT_CASES = [
+    # name, setup(lib), x shape, Cout, mode
+    ("wgrad-xcd-split11", lambda lib: lib.tv_set_wgrad_config(0, 0, 9 * 11), (3, 32, 32, 64), 64, "c3s1"),
+    ("wgrad-xcd-split5-linear", lambda lib: lib.tv_set_wgrad_config(0, 0, 2 * 5), (5 * 640, 128), 256, "linear"),
+    ("wgrad-ring3", lambda lib: (lib.tv_set_wgrad_stages(3), lib.tv_set_wgrad_config(0, 8, 9 * 3)), (2, 32, 32, 192), 192, "c3s1"),
+    ("wgrad-plain-order", lambda lib: (lib.tv_set_wgrad_stages(12), lib.tv_set_wgrad_config(0, 0, 9 * 6)), (2, 32, 32, 64), 128, "c3s1"),
+    ("halo-4wave", lambda lib: (lib.tv_set_igemm_halo(101), lib.tv_set_igemm_config(256, 0, 0, 0)), (2, 32, 16, 192), 192, "c3s1"),
+    ("halo-ring3-all", lambda lib: lib.tv_set_igemm_halo(4), (2, 16, 32, 128), 384, "c3s1"),
+    ("igemm-plain-order", lambda lib: lib.tv_set_igemm_halo(11), (5 * 256 + 40, 128), 640, "linear"),
+    ("igemm-xcd-order", lambda lib: None, (11 * 128 + 7, 64), 320, "linear"),
+]
+
+
+@pytest.mark.parametrize("case", VARIANT_CASES, ids=[c[0] for c in VARIANT_CASES])
+def test_kernel_variants(case):
+    from transvae.hip import ops, _lib
+    name, setup, xs, cout, mode = case
+    lib = _lib.load()
+    ws = (cout,) if mode == "linear" else (cout, 3, 3)
+    x, w, b = _mk(mode, xs, ws, seed=300 + VARIANT_CASES.index(case))
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yref = ref_conv(xr, wr, br, mode, None, None)
+    gy = r16(gen(*yref.shape, seed=6))
+    yref.backward(gy)
+    try:
+        setup(lib)
+        xd = x.to(dev(), BF).requires_grad_(True)
+        wd = w.to(dev()).requires_grad_(True)
+        bd = b.to(dev()).requires_grad_(True)
+        y = ops.conv(xd, wd, bd, None, mode=mode)
+        y.backward(gy.to(dev(), BF))
+        torch.cuda.synchronize()
+        assert rel(y, yref) < 1e-2, "forward"
+        assert rel(xd.grad, xr.grad) < 1e-2, "dgrad"
+        assert rel(wd.grad, wr.grad) < 1e-2, "wgrad"
+        assert rel(bd.grad, br.grad) < 1e-2, "bias grad"
+    finally:
+        lib.tv_set_igemm_halo(1)
+        lib.tv_set_igemm_config(0, 0, 0, 0)
+        lib.tv_set_wgrad_config(0, 0, 0)
+        lib.tv_set_wgrad_stages(0)
+
+
 def test_pack_weight():
     from transvae.hip import ops
     w = gen(40, 9, 72, seed=3)
