@@ -16,6 +16,7 @@ Layer "modes" of :class:`ConvFn` (geometry table in include/transvae_hip.h):
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Optional
 
@@ -47,14 +48,42 @@ def _act_id(act: Optional[str]) -> int:
 # ---------------------------------------------------------------------------------------------
 # raw calls
 # ---------------------------------------------------------------------------------------------
+_pack_cache = None   # dict while a packed_weight_cache() block is active
+
+
+@contextlib.contextmanager
+def packed_weight_cache():
+    """Reuse the bf16 repack of a PARAMETER across the micro-batches of one optimizer step.
+
+    Only views of (or) nn.Parameters are cached, keyed on the parameter object and its version counter, so tensors
+    computed per forward (LayerNorm-folded projections) are always repacked and an in-place update invalidates the
+    entry.  The cache lives for the duration of the block (transvae/parallel.py wraps the micro-batch loop)."""
+    global _pack_cache
+    prev, _pack_cache = _pack_cache, {}
+    try:
+        yield
+    finally:
+        _pack_cache = prev
+
+
 def pack_weight(w: torch.Tensor, want_fwd: bool, want_t: bool, flip: bool):
     """w: fp32 [O, T, I] contiguous -> (bf16 [O,T,I] | None, bf16 [I,T,O] | None)."""
     O, T, I = w.shape
     assert w.dtype == torch.float32 and w.is_contiguous()
+    key = None
+    if _pack_cache is not None:
+        base = w._base if w._base is not None else w
+        if isinstance(base, torch.nn.Parameter):
+            key = (id(base), base._version, w.data_ptr(), O, T, I, want_fwd, want_t, flip)
+            hit = _pack_cache.get(key)
+            if hit is not None:
+                return hit
     d = torch.empty((O, T, I), dtype=BF16, device=w.device) if want_fwd else None
     dt = torch.empty((I, T, O), dtype=BF16, device=w.device) if want_t else None
     lib = L.load()
     L.check(lib.tv_pack_weight(_p(w), _p(d), _p(dt), O, T, I, int(flip), _stream()), "tv_pack_weight")
+    if key is not None:
+        _pack_cache[key] = (d, dt)
     return d, dt
 
 

@@ -62,6 +62,14 @@ def wrap_ddp(model: nn.Module, device: Optional[torch.device], bucket_mb: int = 
                                                find_unused_parameters=False)
 
 
+def _packed_weight_cache(x: torch.Tensor):
+    """The weights do not change between the micro-batches of a step: keep their bf16 repacks (HIP path only)."""
+    if x.is_cuda:
+        from .hip import ops
+        return ops.packed_weight_cache()
+    return contextlib.nullcontext()
+
+
 def train_step(ddp_model: nn.Module, optimizer: torch.optim.Optimizer, x_local: torch.Tensor, micro: int,
                forward_loss: Callable[[nn.Module, torch.Tensor], torch.Tensor], grad_clip: float = 1.0,
                global_batch: Optional[int] = None) -> torch.Tensor:
@@ -79,13 +87,14 @@ def train_step(ddp_model: nn.Module, optimizer: torch.optim.Optimizer, x_local: 
     chunks = micro_batches(n_local, micro)
     total = torch.zeros((), device=x_local.device, dtype=torch.float32)
     optimizer.zero_grad(set_to_none=True)
-    for i, (s, c) in enumerate(chunks):
-        last = i == len(chunks) - 1
-        sync_ctx = contextlib.nullcontext() if (last or not hasattr(ddp_model, "no_sync")) else ddp_model.no_sync()
-        with sync_ctx:
-            loss = forward_loss(ddp_model, x_local[s:s + c]) * (c * world / global_batch)
-            loss.backward()
-        total += loss.detach()
+    with _packed_weight_cache(x_local):
+        for i, (s, c) in enumerate(chunks):
+            last = i == len(chunks) - 1
+            sync_ctx = contextlib.nullcontext() if (last or not hasattr(ddp_model, "no_sync")) else ddp_model.no_sync()
+            with sync_ctx:
+                loss = forward_loss(ddp_model, x_local[s:s + c]) * (c * world / global_batch)
+                loss.backward()
+            total += loss.detach()
     if grad_clip is not None and grad_clip > 0:
         torch.nn.utils.clip_grad_norm_(ddp_model.parameters(), grad_clip)
     optimizer.step()

@@ -224,6 +224,33 @@ def test_kernel_variants(case):
         lib.tv_set_wgrad_stages(0)
 
 
+def test_packed_weight_cache():
+    """bf16 repacks are reused only for (views of) parameters, and an in-place update invalidates them."""
+    from transvae.hip import ops
+    conv = torch.nn.Conv2d(64, 32, 3, padding=1).to(dev()).to(memory_format=torch.channels_last)
+
+    def view():
+        return conv.weight.permute(0, 2, 3, 1).view(32, 9, 64)
+    with ops.packed_weight_cache():
+        a, _ = ops.pack_weight(view(), True, False, False)
+        b, _ = ops.pack_weight(view(), True, False, False)
+        assert a.data_ptr() == b.data_ptr()
+        _, at = ops.pack_weight(view(), False, True, True)          # different request: its own entry
+        assert at is not None and at.shape == (64, 9, 32)
+        with torch.no_grad():
+            conv.weight.add_(1.0)
+        c, _ = ops.pack_weight(view(), True, False, False)
+        assert c.data_ptr() != a.data_ptr()
+        assert torch.equal(c.float().cpu(), view().detach().to(BF).float().cpu())
+        t = torch.randn(32, 9, 64, device=dev())                   # not a parameter: never cached
+        p1, _ = ops.pack_weight(t, True, False, False)
+        p2, _ = ops.pack_weight(t, True, False, False)
+        assert p1.data_ptr() != p2.data_ptr()
+    d1, _ = ops.pack_weight(view(), True, False, False)             # outside the block: no cache
+    d2, _ = ops.pack_weight(view(), True, False, False)
+    assert d1.data_ptr() != d2.data_ptr()
+
+
 def test_pack_weight():
     from transvae.hip import ops
     w = gen(40, 9, 72, seed=3)
