@@ -99,6 +99,20 @@ struct AttnArgs {
 
 constexpr int KV_TILE = 64 * 128;  // bytes of one [64][64] bf16 tile
 
+// Block -> (sequence tile, head, image).  All sequence tiles of one (image, head) stream the same K / V (forward, dq)
+// or Q / dO (dk/dv) rows; placed on ONE XCD they share them through its L2 (workgroups go to XCDs round-robin by linear
+// id, so head-image hb takes the ids congruent to hb mod 8).  Returns false for the padding ids of the last group.
+__device__ __forceinline__ bool attn_block(const AttnArgs& p, int& tile, int& head, int& b) {
+    const int tiles = (p.N + 127) / 128;
+    const int lin = blockIdx.x, j = lin >> 3;
+    tile = j % tiles;
+    const int hb = (j / tiles) * 8 + (lin & 7);
+    if (hb >= p.heads * p.B) return false;
+    head = hb % p.heads;
+    b = hb / p.heads;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: block = 4 waves x 32 queries; loops over 64-key blocks (K: row tile, V: tr tile)
 // ------------------------------------------------------------------------------------------------
@@ -106,13 +120,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K 8 KiB + V 8 KiB)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int head = blockIdx.y, b = blockIdx.z;
+    int tile_x, head, b;
+    if (!attn_block(p, tile_x, head, b)) return;
     const int C = p.heads * 64;
     const size_t ld = (size_t)3 * C;
     const bf16* qbase = p.qkv + (size_t)b * p.N * ld + head * 64;
     const bf16* kbase = qbase + C;
     const bf16* vbase = qbase + 2 * C;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = tile_x * 128 + wave * 32;
     const int qi = q0 + (lane & 31);
     const int h = lane >> 5;
     const bool q_ok = qi < p.N;
@@ -262,13 +277,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int head = blockIdx.y, b = blockIdx.z;
+    int tile_x, head, b;
+    if (!attn_block(p, tile_x, head, b)) return;
     const int C = p.heads * 64;
     const size_t ld = (size_t)3 * C;
     const bf16* qbase = p.qkv + (size_t)b * p.N * ld + head * 64;
     const bf16* kbase = qbase + C;
     const bf16* vbase = qbase + 2 * C;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = tile_x * 128 + wave * 32;
     const int qi = q0 + (lane & 31);
     const int h = lane >> 5;
     const bool q_ok = qi < p.N;
@@ -370,7 +386,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int head = blockIdx.y, b = blockIdx.z;
+    int tile_x, head, b;
+    if (!attn_block(p, tile_x, head, b)) return;
     const int C = p.heads * 64;
     const size_t ld = (size_t)3 * C;
     const bf16* qbase = p.qkv + (size_t)b * p.N * ld + head * 64;
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     const bf16* gbase = p.d_o + (size_t)b * p.N * C + head * 64;
     const float* lse_b = p.lse + ((size_t)b * p.heads + head) * p.N;
     const float* del_b = p.delta + ((size_t)b * p.heads + head) * p.N;
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int k0 = tile_x * 128 + wave * 32;
     const int ki = k0 + (lane & 31);
     const int h = lane >> 5;
     const bool k_ok = ki < p.N;
@@ -497,7 +514,7 @@ extern "C" int tv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, i
     AttnArgs a{};
     a.qkv = (const bf16*)qkv; a.out = (bf16*)o; a.lse = lse; a.zeros = (const char*)tv_zero_page();
     a.B = B; a.N = N; a.heads = heads; a.scale = scale;
-    dim3 grid(tv_cdiv(N, 128), heads, B);
+    dim3 grid((unsigned)(8 * tv_cdiv(N, 128) * tv_cdiv((long long)heads * B, 8)));
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * KV_TILE, (hipStream_t)stream, a);
     TV_CHECK_LAUNCH("tv_attn_fwd");
     return TV_OK;
@@ -518,7 +535,7 @@ extern "C" int tv_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     long long g = (tot + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)g), dim3(256), 0, s, a);
-    dim3 grid(tv_cdiv(N, 128), heads, B);
+    dim3 grid((unsigned)(8 * tv_cdiv(N, 128) * tv_cdiv((long long)heads * B, 8)));
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 4 * KV_TILE, s, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 2 * DKV_STAGE, s, a);
     TV_CHECK_LAUNCH("tv_attn_bwd");
