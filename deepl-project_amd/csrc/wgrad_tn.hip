@@ -464,7 +464,7 @@ int launch_s(const WgradArgs& a, dim3 grid, hipStream_t s) {
 }
 
 template <int TG, int TX>
-int launch(const WgradArgs& a0, hipStream_t s) {
+int launch(const WgradArgs& a0, hipStream_t s, bool plan_only) {
     WgradArgs a = a0;
     const int bkp = g_wgrad_bkp ? g_wgrad_bkp : (TG == 192 ? 64 : 32);   // measured: 64 pays only where 8 waves share the tile
     const int tiles_co = (a.c_out + TG - 1) / TG;
@@ -509,6 +509,7 @@ int launch(const WgradArgs& a0, hipStream_t s) {
     a.chunk_px = (int)chunk;
     const int ny = (int)((a.M + chunk - 1) / chunk);
     a.plain = (ny == 1) ? 1 : 0;
+    if (plan_only) return 100 + a.plain;   // (distinct from the TV_ERR_* codes)
     a.base = (int)base;
     a.ny = ny;
     a.xcd_order = (ny > 1 && xcd) ? 1 : 0;
@@ -553,9 +554,9 @@ extern "C" int tv_set_wgrad_config(int bkp, int waves, int blocks) {
     return 0;
 }
 
-extern "C" int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias,
-                           void* stream) {
-    TV_CHECK_ARG(d && x && gy && dw, "tv_wgrad_tn: null pointer");
+// plan_only: no launch, returns 1 if the call would overwrite dw / dbias (single pixel chunk), 0 if it accumulates
+static int wgrad_impl(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias, void* stream, bool plan_only) {
+    TV_CHECK_ARG(d && (plan_only || (x && gy && dw)), "tv_wgrad_tn: null pointer");
     TV_CHECK_ARG(d->c_in > 0 && d->c_in % 8 == 0, "tv_wgrad_tn: c_in=%d must be a multiple of 8", d->c_in);
     TV_CHECK_ARG(d->c_out > 0 && d->c_out % 8 == 0, "tv_wgrad_tn: c_out=%d must be a multiple of 8", d->c_out);
     TV_CHECK_ARG(d->ldx >= d->c_in && d->ldx % 8 == 0 && d->ldo >= d->c_out && d->ldo % 8 == 0,
@@ -565,7 +566,7 @@ extern "C" int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy,
     TV_CHECK_ARG((d->up_shift | 1) == 1 && (d->dil_mask | 1) == 1, "tv_wgrad_tn: up_shift/dil_mask must be 0 or 1");
     const long long M = (long long)d->batch * d->h_out * d->w_out;
     TV_CHECK_ARG(M < (1ll << 31) && (long long)d->batch * d->h_in * d->w_in < (1ll << 31), "tv_wgrad_tn: too many pixels");
-    if (tv_init() != TV_OK) return TV_ERR_INIT;
+    if (!plan_only && tv_init() != TV_OK) return TV_ERR_INIT;
 
     WgradArgs a;
     a.x = (const bf16*)x;
@@ -583,20 +584,33 @@ extern "C" int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy,
     hipStream_t s = (hipStream_t)stream;
     // 256x256 tiles (8 waves, 128x64 per wave): +5..20 % on linear layers, -9 % on 9-tap convolutions (gemm_sweep, mb 64)
     if ((g_wgrad_tile256 == 1 || (g_wgrad_tile256 == 0 && d->kh * d->kw == 1)) && d->c_out % 256 == 0 && d->c_in % 256 == 0) {
-        launch<256, 256>(a, s);
+        const int r = launch<256, 256>(a, s, plan_only);
+        if (plan_only) return r;
         TV_CHECK_LAUNCH("tv_wgrad_tn");
         return TV_OK;
     }
     const bool g192 = (d->c_out % 192 == 0) && (d->c_out % 128 != 0);
     const bool x192 = (d->c_in % 192 == 0) && (d->c_in % 128 != 0);
     const bool g64 = d->c_out <= 64, x64 = d->c_in <= 64;
-    if (g192 && x192) launch<192, 192>(a, s);
-    else if (g192) { if (x64) launch<192, 64>(a, s); else launch<192, 128>(a, s); }
-    else if (x192) { if (g64) launch<64, 192>(a, s); else launch<128, 192>(a, s); }
-    else if (g64 && x64) launch<64, 64>(a, s);
-    else if (g64) launch<64, 128>(a, s);
-    else if (x64) launch<128, 64>(a, s);
-    else launch<128, 128>(a, s);
+    int r;
+    if (g192 && x192) r = launch<192, 192>(a, s, plan_only);
+    else if (g192) { if (x64) r = launch<192, 64>(a, s, plan_only); else r = launch<192, 128>(a, s, plan_only); }
+    else if (x192) { if (g64) r = launch<64, 192>(a, s, plan_only); else r = launch<128, 192>(a, s, plan_only); }
+    else if (g64 && x64) r = launch<64, 64>(a, s, plan_only);
+    else if (g64) r = launch<64, 128>(a, s, plan_only);
+    else if (x64) r = launch<128, 64>(a, s, plan_only);
+    else r = launch<128, 128>(a, s, plan_only);
+    if (plan_only) return r;
     TV_CHECK_LAUNCH("tv_wgrad_tn");
     return TV_OK;
+}
+
+extern "C" int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias,
+                           void* stream) {
+    return wgrad_impl(d, x, gy, dw, dbias, stream, false);
+}
+
+extern "C" int tv_wgrad_tn_overwrites(const tv_conv_desc* d) {
+    const int r = wgrad_impl(d, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+    return r >= 100 ? r - 100 : -1;
 }

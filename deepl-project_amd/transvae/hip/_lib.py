@@ -40,6 +40,7 @@ SIGNATURES = {
     "tv_igemm_nt": (_I, [_DP, _P, _P, _P, _P, _P, _P, _P]),
     "tv_igemm_nt_actgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P, _P]),
     "tv_wgrad_tn": (_I, [_DP, _P, _P, _P, _P, _P]),
+    "tv_wgrad_tn_overwrites": (_I, [_DP]),
     "tv_pack_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "tv_gn_partial_count": (_LL, [_I, _I, _I]),
     "tv_gn_stats": (_I, [_P, _P, _P, _I, _I, _I, _P]),

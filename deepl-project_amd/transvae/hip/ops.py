@@ -257,12 +257,27 @@ def conv_dgrad(g: _Geo, w, gz, x_shape, residual=None, aux=None, aux_act: int = 
     return dx
 
 
+def _wgrad_overwrites(desc: L.ConvDesc) -> bool:
+    """True when tv_wgrad_tn writes every element of dw / dbias exactly once for this geometry (no pre-zeroing needed).
+    The answer follows the kernel's split-K choice (and its tuning hooks), so the library is asked every time."""
+    r = L.load().tv_wgrad_tn_overwrites(C.byref(desc))
+    if r < 0:
+        raise RuntimeError("tv_wgrad_tn_overwrites: bad descriptor")
+    return r == 1
+
+
+def _grad_buffer(shape, device, zero: bool):
+    return torch.zeros(shape, dtype=torch.float32, device=device) if zero else torch.empty(shape, dtype=torch.float32, device=device)
+
+
 def conv_wgrad_alloc(g: _Geo, w, need_db: bool):
-    """Zeroed outputs of conv_wgrad (allocate on the stream that will consume them)."""
-    db = torch.zeros((g.Cout,), dtype=torch.float32, device=w.device) if need_db else None
+    """Outputs of conv_wgrad (allocated on the stream that will consume them), zeroed only where the kernel accumulates."""
     if g.mode == "shuf":
+        db = torch.zeros((g.Cout,), dtype=torch.float32, device=w.device) if need_db else None
         return torch.zeros((g.Cin, 2, 2, g.Cout // 4), dtype=torch.float32, device=w.device), db
-    return torch.zeros_like(w, memory_format=torch.contiguous_format), db
+    zero = not _wgrad_overwrites(g.fwd_desc(0))
+    db = _grad_buffer((g.Cout,), w.device, zero) if need_db else None
+    return _grad_buffer(tuple(w.shape), w.device, zero), db
 
 
 def conv_wgrad(g: _Geo, w, x, gz, need_db: bool, out=None):
@@ -272,11 +287,11 @@ def conv_wgrad(g: _Geo, w, x, gz, need_db: bool, out=None):
         dw, db = out
         wgrad(g.fwd_desc(0), x, gz, dw, db)
         return dw, db
-    db = torch.zeros((g.Cout,), dtype=torch.float32, device=dev) if need_db else None
     if g.mode != "shuf":
-        dw = torch.zeros_like(w, memory_format=torch.contiguous_format)
+        dw, db = conv_wgrad_alloc(g, w, need_db)
         wgrad(g.fwd_desc(0), x, gz, dw, db)
         return dw, db
+    db = torch.zeros((g.Cout,), dtype=torch.float32, device=dev) if need_db else None
     cq = g.Cout // 4
     d = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
               kh=2, kw=2, stride=2, pad=0)

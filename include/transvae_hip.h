@@ -87,10 +87,14 @@ int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const void* w, con
                         const void* aux_pre_act, int aux_act, void* out, void* stream);
 
 /*
- * Weight gradient of the same layer (fp32, ACCUMULATED into dw / dbias with atomics):
- *   dw[co][ky][kx][ci] += sum_p gy[p][co] * x_gathered[p][ky][kx][ci]
- *   dbias[co]          += sum_p gy[p][co]                       (dbias may be NULL)
+ * Weight gradient of the same layer (fp32):
+ *   dw[co][ky][kx][ci] (+)= sum_p gy[p][co] * x_gathered[p][ky][kx][ci]
+ *   dbias[co]          (+)= sum_p gy[p][co]                       (dbias may be NULL)
  *   gy : [batch, h_out, w_out, c_out] bf16 with `ldo` between pixels
+ * The reduction over pixels is split over workgroups when the layer has few tiles; the partial tiles are then ADDED
+ * into dw / dbias with fp32 atomics and the caller must pass zeroed buffers.  With a single pixel chunk every element
+ * is WRITTEN exactly once and the buffers need no initialisation: tv_wgrad_tn_overwrites(d) says which of the two
+ * tv_wgrad_tn will do for this geometry (1 = overwrites, 0 = accumulates, < 0 = bad descriptor).
  * store_shuffle layers are handled by the caller as the transposed problem (x := the hi-res
  * gradient gathered with 2x2/stride-2 taps, gy := the layer input), so store_shuffle must be 0.
  * Requires c_in % 8 == 0, c_out % 8 == 0.
@@ -98,6 +102,7 @@ int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const void* w, con
  */
 int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias,
                 void* stream);
+int tv_wgrad_tn_overwrites(const tv_conv_desc* d);
 
 /*
  * fp32 -> bf16 weight repack.  src: [O, T, I] fp32 (T = kh*kw taps).
