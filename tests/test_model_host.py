@@ -102,3 +102,37 @@ def test_from_pretrained_parses_name():
     with torch.device("meta"):
         m = TransVAE.from_pretrained("transvae-tiny-f16d32")
     assert m.variant == "tiny" and m.latent_dim == 32 and m.compression_ratio == 16
+
+
+def test_checkpoint_reference_format_round_trip(tmp_path):
+    """the reference's checkpoint dictionary (R/train.py:753-769) written and read back, including a file
+    as the reference itself would write it (contiguous OIHW tensors, contiguous optimizer moments)."""
+    from transvae import TransVAE
+    from transvae.checkpoint import load_checkpoint, save_checkpoint
+    torch.manual_seed(0)
+    m = TransVAE(config=dict(O.MICRO), variant="micro", latent_dim=4)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0)
+    for p in m.parameters():
+        p.grad = torch.randn_like(p) * 1e-2
+    opt.step()
+    path = str(tmp_path / "ckpt.pth")
+    save_checkpoint(m, opt, epoch=3, global_step=1234, path=path, args={"lr": 1e-4, "variant": "micro"})
+    raw = torch.load(path, weights_only=True)
+    assert set(raw) == {"epoch", "global_step", "model_state_dict", "optimizer_state_dict", "args"}
+    assert all(v.is_contiguous() for v in raw["model_state_dict"].values())
+    m2 = TransVAE(config=dict(O.MICRO), variant="micro", latent_dim=4)
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0)
+    meta = load_checkpoint(path, m2, opt2)
+    assert meta["epoch"] == 3 and meta["global_step"] == 1234 and meta["args"]["variant"] == "micro"
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    for pa, pb in zip(m.parameters(), m2.parameters()):
+        sa, sb = opt.state[pa], opt2.state[pb]
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+        assert sb["exp_avg"].stride() == pb.stride()       # moments follow the (channels_last) parameter layout
+    # a reference-written file: same keys, plain contiguous tensors
+    ref_like = {"epoch": 0, "model_state_dict": {k: v.clone().contiguous() for k, v in m.state_dict().items()},
+                "optimizer_state_dict": opt.state_dict(), "args": {}}
+    torch.save(ref_like, path)
+    meta = load_checkpoint(path, m2, opt2)
+    assert meta["global_step"] == 0
