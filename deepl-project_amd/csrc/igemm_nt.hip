@@ -63,6 +63,9 @@ struct IgemmArgs {
 #ifndef TV_GENERIC_BURST
 #define TV_GENERIC_BURST 1    // same for the generic 256x256 tile (A/B on the 768-channel linear layers: +2-5 %)
 #endif
+#ifndef TV_DMA_STAGGER
+#define TV_DMA_STAGGER 0    // two code copies with shifted DMA slots for waves 0-3 / 4-7: measured -3 % (register pressure)
+#endif
 #ifndef TV_RD_THREAD
 #define TV_RD_THREAD 0
 #endif
@@ -929,7 +932,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
 #endif
             }
         };
-        auto mfma_half = [&](const bf16x8 (&fa)[MF], const bf16x8 (&fb)[NF], auto issue, auto rd) {
+        auto mfma_half = [&](const bf16x8 (&fa)[MF], const bf16x8 (&fb)[NF], auto issue, auto rd, auto phase_c) {
+            // DMA slots: waves 4-7 (PH = 1) issue half a gap before waves 0-3, so that the eight waves of a block do not
+            // queue at the address pipe at the same MFMA index (two code copies; a per-wave branch costs more than it saves)
+            constexpr int PH = decltype(phase_c)::value;
+            constexpr int SLOT = PH ? (HGAP - 1) / 2 : HGAP - 1;
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
@@ -945,14 +952,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                         rd(idx / RGAP);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (idx % HGAP == HGAP - 1 && idx / HGAP < NIS) {
+                    if (idx % HGAP == SLOT && idx / HGAP < NIS) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue(idx / HGAP);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
         };
-        auto run = [&](auto loader_c) {
+        auto run = [&](auto loader_c, auto phase_c) {
             constexpr bool LOADER = decltype(loader_c)::value;
             if constexpr (LOADER) {
 #pragma unroll
@@ -978,7 +985,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                     if constexpr (RD_THREAD) asm volatile("" : "+v"(hpb));   // pin the address arithmetic to this tap (see compute)
                     if constexpr (!RD_THREAD) read_half(acur, bslot, toff, 1, f1a, f1b);
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma_half(f0a, f0b, [](int) {}, [&](int k) { read_piece(acur, bslot, hpb, toff, 1, f1a, f1b, k); });
+                    mfma_half(f0a, f0b, [](int) {}, [&](int k) { read_piece(acur, bslot, hpb, toff, 1, f1a, f1b, k); }, phase_c);
                     __builtin_amdgcn_sched_barrier(0);
                     TV_T(3);
                     const bool go_on = tap < 8 || more;
@@ -1012,9 +1019,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                             } else if (tap < ATAPS && tap * A_PT + (q - B_IT) < A_IT && more) {
                                 issue_a(anxt, tap * A_PT + (q - B_IT), ch + 1);
                             }
-                        }, rd_next);
+                        }, rd_next, phase_c);
                     } else {
-                        mfma_half(f1a, f1b, [](int) {}, rd_next);
+                        mfma_half(f1a, f1b, [](int) {}, rd_next, phase_c);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     TV_T(4);
@@ -1023,10 +1030,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
             }
         };
         if constexpr (NWL == NW) {
-            run(std::true_type{});
+            if constexpr (NW == 8 && HGAP >= 4 && TV_DMA_STAGGER) {
+                if (wave < 4) run(std::true_type{}, std::integral_constant<int, 0>{});
+                else run(std::true_type{}, std::integral_constant<int, 1>{});
+            } else {
+                run(std::true_type{}, std::integral_constant<int, 0>{});
+            }
         } else {
-            if (wave < NWL) run(std::true_type{});
-            else run(std::false_type{});
+            if (wave < NWL) run(std::true_type{}, std::integral_constant<int, 0>{});
+            else run(std::false_type{}, std::integral_constant<int, 0>{});
         }
     } else {
         // ---- main loop: one barrier per (chunk, tap).  The weight slab of step t + BST - 1 and one halo piece of the next
