@@ -77,6 +77,45 @@ __device__ __forceinline__ bf16x8 read_cols(const char* tile, int r0, int dblk, 
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// The same two readers with the per-lane part of the address precomputed (it does not depend on the key block): inside
+// the loops only compile-time byte offsets remain (row0 * 128: the swizzles repeat every 16 rows), so a fragment read
+// costs no vector ALU work -- the forward loop spent 62 of its ~190 non-transcendental VALU instructions on addresses.
+//   rows: off_rows[st] = (lane&31)*128 + ((2*st + lane>>5) ^ swz_row(lane&31))*16         + row0*128 (row0 % 16 == 0)
+//   cols: off_cols[db] = ra*128 + ((db*4 + (g&1)*2 + pp>>1) ^ swz(ra))*16 + (pp&1)*8,  ra = 4h+q;  second half: ra + 8
+__device__ __forceinline__ void rows_offsets(int lane, int (&off)[4]) {
+    const int row = lane & 31;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) off[st] = row * 128 + (((2 * st + (lane >> 5)) ^ swz_row(row)) << 4);
+}
+template <bool TR>
+__device__ __forceinline__ void cols_offsets(int lane, int (&off)[2], int (&offh)[2]) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int ra = 4 * (g >> 1) + q, rb = ra + 8;   // (the row swizzle of the second half differs: its own offset)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int chunk = db * 4 + (g & 1) * 2 + (pp >> 1);
+        off[db] = ra * 128 + ((chunk ^ (TR ? swz_tr(ra) : swz_row(ra))) << 4) + (pp & 1) * 8;
+        offh[db] = rb * 128 + ((chunk ^ (TR ? swz_tr(rb) : swz_row(rb))) << 4) + (pp & 1) * 8;
+    }
+}
+__device__ __forceinline__ bf16x8 read_rows_at(const char* tile, int off, int row0) {
+    return *(const bf16x8*)(tile + off + row0 * 128);
+}
+// (the asm read has no compiler-visible addressing mode: the constant part goes into its offset field by hand)
+template <int BYTES>
+__device__ __forceinline__ bf16x4 lds_tr16_imm(unsigned a) {
+    bf16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(BYTES) : "memory");
+    return r;
+}
+template <int R0>
+__device__ __forceinline__ bf16x8 read_cols_at(const char* tile, int off, int offh) {
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)tile;
+    const bf16x4 lo = lds_tr16_imm<R0 * 128>(a + off);
+    const bf16x4 hi = lds_tr16_imm<R0 * 128>(a + offh);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 // registers 8s..8s+7 of an accumulator tile -> bf16 fragment (B operand of the next MFMA)
 __device__ __forceinline__ bf16x8 pack_acc(const f32x16& a, int s) {
     bf16x8 r;
@@ -146,6 +185,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const float c2 = p.scale * 1.4426950408889634f;
     const int nblk = (p.N + 63) / 64;
 
+    int off_k[4], off_v[2], off_vh[2];
+    rows_offsets(lane, off_k);
+    cols_offsets<true>(lane, off_v, off_vh);
     stage_rows<false>(smem, kbase, 0, p.N, ld, 64, wave, lane, p.zeros);
     stage_rows<true>(smem + KV_TILE, vbase, 0, p.N, ld, 64, wave, lane, p.zeros);
     for (int t = 0; t < nblk; ++t) {
@@ -164,16 +206,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) s[kt] = mfma32(read_rows(kt_, kt * 32, st, lane), qf[st], s[kt]);
+            for (int st = 0; st < 4; ++st) s[kt] = mfma32(read_rows_at(kt_, off_k[st], kt * 32), qf[st], s[kt]);
         }
         // V^T fragments of the whole 64-key block (transposed reads, asm): issued now, consumed after the softmax
         bf16x8 vfr[2][2][2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) vfr[kt][ss][db] = read_cols<true>(vt_, kt * 32 + 16 * ss, db, lane);
+        for (int db = 0; db < 2; ++db) {
+            vfr[0][0][db] = read_cols_at<0>(vt_, off_v[db], off_vh[db]);
+            vfr[0][1][db] = read_cols_at<16>(vt_, off_v[db], off_vh[db]);
+            vfr[1][0][db] = read_cols_at<32>(vt_, off_v[db], off_vh[db]);
+            vfr[1][1][db] = read_cols_at<48>(vt_, off_v[db], off_vh[db]);
+        }
         // online softmax over this lane's 32 keys (+ the other half-wave's 32); scores stay unscaled, the scale
         // rides in the exp2 FMA:  p = exp2(s*c2 - m*c2)
         const int kv0 = t * 64;
@@ -311,6 +354,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) dqt[0][i] = dqt[1][i] = 0.f;
     const int nblk = (p.N + 63) / 64;
+    int off_r[4], off_c[2], off_ch[2];
+    rows_offsets(lane, off_r);
+    cols_offsets<false>(lane, off_c, off_ch);
 
     stage_rows<false>(smem, kbase, 0, p.N, ld, 64, wave, lane, p.zeros);
     stage_rows<false>(smem + KV_TILE, vbase, 0, p.N, ld, 64, wave, lane, p.zeros);
@@ -336,14 +382,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
             }
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                s = mfma32(read_rows(kt_, kt * 32, st, lane), qf[st], s);
-                dp = mfma32(read_rows(vt_, kt * 32, st, lane), gf[st], dp);
+                s = mfma32(read_rows_at(kt_, off_r[st], kt * 32), qf[st], s);
+                dp = mfma32(read_rows_at(vt_, off_r[st], kt * 32), gf[st], dp);
             }
             bf16x8 kfr[2][2];   // K^T fragments (transposed asm reads): in flight during the exponentials
 #pragma unroll
-            for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) kfr[ss][db] = read_cols<false>(kt_, kt * 32 + 16 * ss, db, lane);
+            for (int db = 0; db < 2; ++db) {
+                if (kt == 0) {
+                    kfr[0][db] = read_cols_at<0>(kt_, off_c[db], off_ch[db]);
+                    kfr[1][db] = read_cols_at<16>(kt_, off_c[db], off_ch[db]);
+                } else {
+                    kfr[0][db] = read_cols_at<32>(kt_, off_c[db], off_ch[db]);
+                    kfr[1][db] = read_cols_at<48>(kt_, off_c[db], off_ch[db]);
+                }
+            }
             if (partial) {   // ragged last block: keys >= N must not contribute (P = 0): push their score to -inf
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -418,6 +470,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     const float c2 = p.scale * 1.4426950408889634f;
     const float inv_scale = 1.0f / p.scale;
     const int ntile = (p.N + 31) / 32;
+    int off_r[4], off_c[2], off_ch[2];
+    rows_offsets(lane, off_r);
+    cols_offsets<false>(lane, off_c, off_ch);
 
     auto stage = [&](int t, char* sb) {
         stage_rows<false>(sb, qbase, t * 32, p.N, ld, 32, wave, lane, p.zeros);
@@ -451,17 +506,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         }
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-            s = mfma32(read_rows(qt_, 0, st, lane), kf[st], s);
-            dp = mfma32(read_rows(gt_, 0, st, lane), vf[st], dp);
+            s = mfma32(read_rows_at(qt_, off_r[st], 0), kf[st], s);
+            dp = mfma32(read_rows_at(gt_, off_r[st], 0), vf[st], dp);
         }
         bf16x8 gfr[2][2], qfr[2][2];   // dO^T and Q^T fragments (transposed asm reads)
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                gfr[ss][db] = read_cols<false>(gt_, 16 * ss, db, lane);
-                qfr[ss][db] = read_cols<false>(qt_, 16 * ss, db, lane);
-            }
+        for (int db = 0; db < 2; ++db) {
+            gfr[0][db] = read_cols_at<0>(gt_, off_c[db], off_ch[db]);
+            gfr[1][db] = read_cols_at<16>(gt_, off_c[db], off_ch[db]);
+            qfr[0][db] = read_cols_at<0>(qt_, off_c[db], off_ch[db]);
+            qfr[1][db] = read_cols_at<16>(qt_, off_c[db], off_ch[db]);
+        }
         // queries beyond N have Q = dO = 0, lse = delta = 0  =>  P = 1, dS = 0, and dO^T P adds 0
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
