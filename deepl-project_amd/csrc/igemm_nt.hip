@@ -153,7 +153,17 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
         const int n = nw0 + c8 * 8;
         if (m >= p.M || n >= p.N) continue;
         size_t off;
-        if (p.shuffle) {
+        if (p.shuffle == 2) {   // polyphase upsampling conv: grid (H+1) x (W+1), phase (py, px) of cell (sy, sx) is pixel
+            const int sb = m / hw;                      //   (2*sy - py, 2*sx - px) of the [2H, 2W] output; cells on the rim
+            const int rr = m - sb * hw;                 //   have phases that fall outside
+            const int sy = rr / p.w_out, sx = rr - sy * p.w_out;
+            const int qs = n / cq;
+            const int c = n - qs * cq;
+            const int Y = 2 * sy - (qs >> 1), X = 2 * sx - (qs & 1);
+            const int H2 = 2 * (p.h_out - 1), W2 = 2 * (p.w_out - 1);
+            if ((unsigned)Y >= (unsigned)H2 || (unsigned)X >= (unsigned)W2) continue;
+            off = (((size_t)sb * H2 + Y) * W2 + X) * p.ldo + c;
+        } else if (p.shuffle) {
             const int sb = m / hw;
             const int rr = m - sb * hw;
             const int sy = rr / p.w_out, sx = rr - sy * p.w_out;
@@ -1302,6 +1312,7 @@ static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, co
     TV_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "tv_igemm_nt: bad taps");
     TV_CHECK_ARG((d->up_shift | 1) == 1 && (d->dil_mask | 1) == 1, "tv_igemm_nt: up_shift/dil_mask must be 0 or 1");
     TV_CHECK_ARG(d->act >= 0 && d->act <= 2, "tv_igemm_nt: unknown activation %d", d->act);
+    TV_CHECK_ARG(d->store_shuffle >= 0 && d->store_shuffle <= 2, "tv_igemm_nt: store_shuffle must be 0, 1 or 2");
     const long long M = (long long)d->batch * d->h_out * d->w_out;
     TV_CHECK_ARG(M < (1ll << 31) && (long long)d->batch * d->h_in * d->w_in < (1ll << 31), "tv_igemm_nt: too many pixels");
     if (d->store_shuffle) {

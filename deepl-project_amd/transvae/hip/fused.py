@@ -99,7 +99,7 @@ def _wg(ctx, iw, ib, geo, w, x, gz):
     need_w, need_b = ctx.needs_input_grad[iw], ctx.needs_input_grad[ib]
     if not (need_w or need_b):
         return None, None
-    if _SIDE["on"] and geo.mode != "shuf":
+    if _SIDE["on"] and geo.mode not in ("shuf", "c3up"):
         out = ops.conv_wgrad_alloc(geo, w, need_b)
         main = torch.cuda.current_stream()
         side = _side_stream(x.device)

@@ -186,13 +186,19 @@ def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre: bool):
     assert w.dtype == torch.float32
     w = w.contiguous()
     g = _Geo(mode, x, w)
-    wb, _ = pack_weight(w.view(g.Cout, g.KH * g.KW, g.Cin), True, False, False)
     out = torch.empty(g.out_shape, dtype=BF16, device=x.device)
     pre = torch.empty_like(out) if (want_pre and act_id != L.ACT_NONE) else None
     if residual is not None:
         assert residual.shape == out.shape and residual.dtype == BF16 and residual.is_contiguous()
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == g.Cout
+    if mode == "c3up":   # polyphase: one 2x2-footprint GEMM on the (H+1) x (W+1) cell grid, four phases as column quadrants
+        wb = _up_fwd_weight(w, g.Cout, g.Cin)
+        d = _desc(batch=g.B, h_in=g.H, w_in=g.W, c_in=g.Cin, ldx=g.Cin, h_out=g.H + 1, w_out=g.W + 1, c_out=4 * g.Cout,
+                  ldo=g.Cout, kh=2, kw=2, stride=1, pad=1, act=act_id, store_shuffle=2)
+        igemm(d, x, wb, bias.repeat(4) if bias is not None else None, residual, pre, out)
+        return out, pre, g, w
+    wb, _ = pack_weight(w.view(g.Cout, g.KH * g.KW, g.Cin), True, False, False)
     igemm(g.fwd_desc(act_id), x, wb, bias, residual, pre, out)
     return out, pre, g, w
 
@@ -205,6 +211,66 @@ def _igemm_bwd(desc, gz, wt, residual, aux, aux_act, dx):
         lib = L.load()
         L.check(lib.tv_igemm_nt_actgrad(C.byref(desc), _p(gz), _p(wt), _p(residual), _p(aux), aux_act, _p(dx), _stream()),
                 "tv_igemm_nt_actgrad")
+
+
+# nearest-x2 upsample followed by a 3x3 / pad-1 convolution, in polyphase form.  Output row Y = 2y' - py of the [2H]
+# grid reads the input rows y'-1, y' of the [H] grid (cell y' of the (H+1)-cell grid of neighbouring row pairs), because
+# upsampled rows 2r, 2r+1 are both input row r:
+#     py = 0:  row y'-1 gets w[ky=0],        row y' gets w[1] + w[2]
+#     py = 1:  row y'-1 gets w[0] + w[1],    row y' gets w[2]                       (and the same along x)
+# so each output phase is a 2x2 convolution of the INPUT: 4 taps per output pixel instead of 9, and nothing of the
+# upsampled tensor is ever read.  _UP_SETS[p][t] = the ky folded into tap t of phase p.
+_UP_SETS = (((0,), (1, 2)), ((0, 1), (2,)))
+
+
+def _up_fwd_weight(w: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
+    """Forward operand: bf16 [4*Cout, 2, 2, Cin], row (2*py+px)*Cout + co, tap (ty, tx)."""
+    w4 = w.view(Cout, 3, 3, Cin)
+    wf = torch.empty((4, Cout, 2, 2, Cin), dtype=torch.float32, device=w.device)
+    for py in (0, 1):
+        for px in (0, 1):
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    acc = None
+                    for ky in _UP_SETS[py][ty]:
+                        for kx in _UP_SETS[px][tx]:
+                            acc = w4[:, ky, kx, :] if acc is None else acc + w4[:, ky, kx, :]
+                    wf[2 * py + px, :, ty, tx, :] = acc
+    return wf.to(BF16).view(4 * Cout, 2, 2, Cin)
+
+
+# The adjoint is a 4x4 / stride-2 / pad-1 convolution of the high-resolution gradient: input row r receives output rows
+# Y = 2r + d, d = -1 .. 2 (tap t = d + 1), through  d = -1: w[2],  d = 0: w[1] + w[2],  d = 1: w[0] + w[1],  d = 2: w[0].
+_UP_ADJ = ((2,), (1, 2), (0, 1), (0,))
+
+
+def _up_dgrad_weight(w: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
+    """Data-gradient operand: bf16 [Cin, 4, 4, Cout]."""
+    w4 = w.view(Cout, 3, 3, Cin)
+    wd = torch.empty((Cin, 4, 4, Cout), dtype=torch.float32, device=w.device)
+    for ty in range(4):
+        for tx in range(4):
+            acc = None
+            for ky in _UP_ADJ[ty]:
+                for kx in _UP_ADJ[tx]:
+                    acc = w4[:, ky, kx, :] if acc is None else acc + w4[:, ky, kx, :]
+            wd[:, ty, tx, :] = acc.t()
+    return wd.to(BF16)
+
+
+def _up_fold_wgrad(d16: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
+    """[Cin, 4, 4, Cout] gradient of the 4x4 adjoint operand -> [Cout, 3, 3, Cin] gradient of the 3x3 weight
+    (tap t of the adjoint contains w[ky] for ky in _UP_ADJ[t], so dw[ky] sums the taps that contain it)."""
+    taps = tuple(tuple(t for t in range(4) if k in _UP_ADJ[t]) for k in range(3))   # ((2,3), (1,2), (0,1))
+    dw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=d16.device)
+    for ky in range(3):
+        for kx in range(3):
+            acc = None
+            for ty in taps[ky]:
+                for tx in taps[kx]:
+                    acc = d16[:, ty, tx, :] if acc is None else acc + d16[:, ty, tx, :]
+            dw[:, ky, kx, :] = acc.t()
+    return dw
 
 
 def _s2_parity_weight(w: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
@@ -233,10 +299,10 @@ def conv_dgrad(g: _Geo, w, gz, x_shape, residual=None, aux=None, aux_act: int = 
     dev = gz.device
     if m == "unshuf":  # GEMM rows n = (dy,dx,c): transpose the flattened [Cout, 4*Cin] matrix
         _, wt = pack_weight(w.view(g.Cout, 1, T * g.Cin), False, True, False)
-    elif m == "c3s2":
-        wt = None      # (parity formulation below builds its own operand)
+    elif m in ("c3s2", "c3up"):
+        wt = None      # (parity / polyphase formulations below build their own operands)
     else:              # [Cin][taps (reversed for 3x3)][Cout]
-        _, wt = pack_weight(w.view(g.Cout, T, g.Cin), False, True, m in ("c3s1", "c3s2", "c3up"))
+        _, wt = pack_weight(w.view(g.Cout, T, g.Cin), False, True, m == "c3s1")
     dx = torch.empty(x_shape, dtype=BF16, device=dev)
     if m == "linear":
         d = _desc(batch=g.B, h_in=1, w_in=1, c_in=g.Cout, ldx=g.Cout, h_out=1, w_out=1, c_out=g.Cin, ldo=g.Cin, kh=1, kw=1)
@@ -254,16 +320,11 @@ def conv_dgrad(g: _Geo, w, gz, x_shape, residual=None, aux=None, aux_act: int = 
         d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.Ho, w_out=g.Wo, c_out=4 * g.Cin, ldo=g.Cin,
                   kh=2, kw=2, stride=1, pad=0, store_shuffle=1)
         _igemm_bwd(d, gz, wd, residual, aux, aux_act, dx)
-    elif m == "c3up":
-        du = torch.empty((g.B, g.Ho, g.Wo, g.Cin), dtype=BF16, device=dev)
-        d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.Ho, w_out=g.Wo, c_out=g.Cin, ldo=g.Cin,
-                  kh=3, kw=3, stride=1, pad=1)
-        igemm(d, gz, wt, None, None, None, du)
-        L.check(lib.tv_pool2x2_sum(_p(du), _p(dx), g.B, g.H, g.W, g.Cin, _stream()), "tv_pool2x2_sum")
-        if residual is not None:
-            L.check(lib.tv_add_(_p(dx), _p(residual), dx.numel(), _stream()), "tv_add_")
-        if aux is not None:
-            L.check(lib.tv_act_bwd(_p(aux), _p(dx), _p(dx), dx.numel(), aux_act, _stream()), "tv_act_bwd")
+    elif m == "c3up":   # adjoint of the polyphase form: 4x4 / stride-2 / pad-1 convolution of the high-resolution gradient
+        wd = _up_dgrad_weight(w, g.Cout, g.Cin)
+        d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
+                  kh=4, kw=4, stride=2, pad=1)
+        _igemm_bwd(d, gz, wd, residual, aux, aux_act, dx)
     elif m == "unshuf":
         # dx[b,2oy+dy,2ox+dx,c] = sum_co gz[b,oy,ox,co] W[co,dy,dx,c]  -> GEMM with shuffled store
         d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.Ho, w_out=g.Wo, c_out=4 * g.Cin, ldo=g.Cin,
@@ -306,6 +367,16 @@ def conv_wgrad_alloc(g: _Geo, w, need_db: bool):
 def conv_wgrad(g: _Geo, w, x, gz, need_db: bool, out=None):
     """(dw in w's layout, dbias | None), fp32.  `out` = buffers from conv_wgrad_alloc (optional)."""
     dev = x.device
+    if g.mode == "c3up":
+        # weight gradient of the polyphase form = that of its adjoint conv (gathered operand: the high-resolution
+        # gradient under 4x4 / stride-2 taps; the other operand: the layer input), folded back onto the 3x3 taps
+        d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
+                  kh=4, kw=4, stride=2, pad=1)
+        d16 = _grad_buffer((g.Cin, 4, 4, g.Cout), dev, not _wgrad_overwrites(d))
+        wgrad(d, gz, x, d16, None)
+        dw = _up_fold_wgrad(d16, g.Cout, g.Cin)
+        db = gz.view(-1, g.Cout).sum(0, dtype=torch.float32) if need_db else None
+        return dw, db
     if out is not None and g.mode != "shuf":
         dw, db = out
         wgrad(g.fwd_desc(0), x, gz, dw, db)

@@ -60,7 +60,11 @@ typedef struct tv_conv_desc {
     int up_shift, dil_mask;
     int act;           /* TV_ACT_* applied after bias, before residual */
     int store_shuffle; /* 1: pixel_shuffle(2) on store: out is [batch, 2*h_out, 2*w_out, c_out/4],
-                          output column n = (dy*2+dx)*(c_out/4) + c  (upsample.py:121-123) */
+                          output column n = (dy*2+dx)*(c_out/4) + c  (upsample.py:121-123)
+                          2: polyphase form of nearest-x2 upsample + 3x3 conv (upsample.py:94-95): the GEMM runs on the
+                          (H+1) x (W+1) grid of 2x2 input neighbourhoods (kh = kw = 2, pad = 1, h_out = H+1, w_out = W+1),
+                          column quadrant (py*2+px) of cell (y, x) is output pixel (2y - py, 2x - px) of the
+                          [batch, 2H, 2W, c_out/4] result; phases that fall outside are dropped */
 } tv_conv_desc;
 
 /*

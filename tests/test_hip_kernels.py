@@ -79,6 +79,7 @@ CONV_CASES = [
     ("c3s2", (2, 12, 8, 64), (128, 3, 3), None, True),    # even size: data gradient by output parity
     ("c3s2", (1, 16, 24, 96), (64, 3, 3), "silu", False),
     ("c3up", (2, 5, 6, 128), (64, 3, 3), None, False),
+    ("c3up", (1, 8, 16, 64), (96, 3, 3), "silu", True),    # polyphase form with activation, saved pre-activation, residual
     ("unshuf", (2, 8, 12, 64), (128, 2, 2), None, True),
     ("shuf", (2, 6, 5, 128), (256, 1, 1), None, False),
 ]
