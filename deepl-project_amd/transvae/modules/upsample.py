@@ -7,7 +7,7 @@ materialises for layout reasons:
   Downsample   dc  = 2x2/stride-2 gather conv             == pixel_unshuffle(2) + 1x1   (:60-61)
                out = conv3x3_s2(SiLU(conv3x3(x))) + dc    residual add in the conv epilogue
   Upsample     dc  = GEMM with pixel-shuffled store       == 1x1 + pixel_shuffle(2)     (:121-123)
-               h   = SiLU(conv3x3(nearest2(x)))           upsample folded into the gather index
+               h   = SiLU(conv3x3(nearest2(x)))           polyphase form: four 2x2 convs of x (hip/ops.py)
                out = conv3x3(h) + dc                      residual add in the conv epilogue
 """
 from __future__ import annotations
