@@ -49,8 +49,8 @@ def gn_silu_bwd(x, dy, dres, mr, gamma, beta, groups):
     L.check(lib.tv_gn_silu_bwd_reduce(_p(x), _p(dy), _p(mr), _p(gamma), _p(beta), _p(red), _p(part), B, H * W, Cc, groups,
                                       _stream()), "tv_gn_silu_bwd_reduce")
     dx = torch.empty_like(x)
-    dg = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
-    db = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
+    dg = ops.zeros_f32((Cc,), x.device)
+    db = ops.zeros_f32((Cc,), x.device)
     L.check(lib.tv_gn_silu_bwd_apply(_p(x), _p(dy), _p(dres), _p(mr), _p(red), _p(gamma), _p(beta), _p(dx), _p(dg), _p(db),
                                      B, H * W, Cc, groups, _stream()), "tv_gn_silu_bwd_apply")
     return dx, dg, db
@@ -66,7 +66,7 @@ def rownorm_fwd(x, w, mode, eps_rms, eps_ln):
 def rownorm_bwd(x, w, dy, dres, mode, eps_rms, eps_ln):
     T, Cc = x.shape
     dx = torch.empty_like(x)
-    dw = torch.zeros((Cc,), dtype=torch.float32, device=x.device) if mode == 1 else None
+    dw = ops.zeros_f32((Cc,), x.device) if mode == 1 else None
     L.check(L.load().tv_rownorm_bwd(_p(x), _p(w), _p(dy), _p(dres), _p(dx), _p(dw), T, Cc, mode, eps_rms, eps_ln, _stream()),
             "tv_rownorm_bwd")
     return dx, dw

@@ -350,15 +350,42 @@ def _wgrad_overwrites(desc: L.ConvDesc) -> bool:
     return r == 1
 
 
+# Small zero-initialised fp32 buffers (bias / norm-weight gradients, split-K weight gradients of small layers) are carved
+# out of a pre-zeroed slab: a backward pass asked for ~770 of them per micro-batch, each a separate ~5 us fill kernel on a
+# GPU that is otherwise saturated (profiles/: FillFunctor 0.7 % of the step).  A region is handed out once and never reused;
+# the slab lives as long as any tensor carved from it.
+_ZERO_SLAB_BYTES = 32 << 20
+_ZERO_SMALL_BYTES = 1 << 20
+_zero_slabs = {}     # (device, stream) -> [slab tensor (uint8), offset]
+
+
+def zeros_f32(shape, device) -> torch.Tensor:
+    n = 1
+    for v in shape:
+        n *= int(v)
+    nbytes = n * 4
+    if nbytes == 0 or nbytes > _ZERO_SMALL_BYTES or device.type != "cuda":
+        return torch.zeros(shape, dtype=torch.float32, device=device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ent = _zero_slabs.get(key)
+    need = (nbytes + 255) & ~255
+    if ent is None or ent[1] + need > _ZERO_SLAB_BYTES:
+        ent = [torch.zeros((_ZERO_SLAB_BYTES,), dtype=torch.uint8, device=device), 0]
+        _zero_slabs[key] = ent
+    off = ent[1]
+    ent[1] = off + need
+    return ent[0][off:off + nbytes].view(torch.float32).view(shape)
+
+
 def _grad_buffer(shape, device, zero: bool):
-    return torch.zeros(shape, dtype=torch.float32, device=device) if zero else torch.empty(shape, dtype=torch.float32, device=device)
+    return zeros_f32(shape, device) if zero else torch.empty(shape, dtype=torch.float32, device=device)
 
 
 def conv_wgrad_alloc(g: _Geo, w, need_db: bool):
     """Outputs of conv_wgrad (allocated on the stream that will consume them), zeroed only where the kernel accumulates."""
     if g.mode == "shuf":
-        db = torch.zeros((g.Cout,), dtype=torch.float32, device=w.device) if need_db else None
-        return torch.zeros((g.Cin, 2, 2, g.Cout // 4), dtype=torch.float32, device=w.device), db
+        db = zeros_f32((g.Cout,), w.device) if need_db else None
+        return zeros_f32((g.Cin, 2, 2, g.Cout // 4), w.device), db
     zero = not _wgrad_overwrites(g.fwd_desc(0))
     db = _grad_buffer((g.Cout,), w.device, zero) if need_db else None
     return _grad_buffer(tuple(w.shape), w.device, zero), db
@@ -385,17 +412,17 @@ def conv_wgrad(g: _Geo, w, x, gz, need_db: bool, out=None):
         dw, db = conv_wgrad_alloc(g, w, need_db)
         wgrad(g.fwd_desc(0), x, gz, dw, db)
         return dw, db
-    db = torch.zeros((g.Cout,), dtype=torch.float32, device=dev) if need_db else None
+    db = zeros_f32((g.Cout,), dev) if need_db else None
     cq = g.Cout // 4
     d = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
               kh=2, kw=2, stride=2, pad=0)
-    dwt = torch.zeros((g.Cin, 2, 2, cq), dtype=torch.float32, device=dev)
+    dwt = zeros_f32((g.Cin, 2, 2, cq), dev)
     wgrad(d, gz, x, dwt, None)     # the transposed problem: gathered operand = hi-res gradient
     dw = dwt.permute(1, 2, 3, 0).reshape(g.Cout, 1, 1, g.Cin).contiguous()
     if need_db:
         d1 = _desc(batch=g.B, h_in=2 * g.H, w_in=2 * g.W, c_in=cq, ldx=cq, h_out=g.H, w_out=g.W, c_out=8, ldo=8,
                    kh=2, kw=2, stride=2, pad=0)
-        tmp = torch.zeros((8, 2, 2, cq), dtype=torch.float32, device=dev)
+        tmp = zeros_f32((8, 2, 2, cq), dev)
         wgrad(d1, gz, _ones(g.B * g.H * g.W, dev), tmp, None)
         db = tmp[0].reshape(g.Cout).contiguous()
     return dw, db
@@ -484,8 +511,8 @@ class GroupNormSiluFn(torch.autograd.Function):
         L.check(lib.tv_gn_silu_bwd_reduce(_p(x), _p(gy), _p(mr), _p(gamma), _p(beta), _p(red), _p(part), B, H * W, Cc, ctx.groups,
                                           _stream()), "tv_gn_silu_bwd_reduce")
         dx = torch.empty_like(x)
-        dg = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
-        db = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
+        dg = zeros_f32((Cc,), x.device)
+        db = zeros_f32((Cc,), x.device)
         L.check(lib.tv_gn_silu_bwd_apply(_p(x), _p(gy), None, _p(mr), _p(red), _p(gamma), _p(beta), _p(dx), _p(dg), _p(db),
                                          B, H * W, Cc, ctx.groups, _stream()), "tv_gn_silu_bwd_apply")
         return dx, dg, db, None, None
@@ -523,7 +550,7 @@ class RowNormFn(torch.autograd.Function):
         lib = L.load()
         gy = gy.contiguous()
         dx = torch.empty_like(x)
-        dw = torch.zeros((Cc,), dtype=torch.float32, device=x.device) if ctx.mode == 1 else None
+        dw = zeros_f32((Cc,), x.device) if ctx.mode == 1 else None
         L.check(lib.tv_rownorm_bwd(_p(x), _p(w), _p(gy), None, _p(dx), _p(dw), T, Cc, ctx.mode, ctx.eps[0], ctx.eps[1], _stream()),
                 "tv_rownorm_bwd")
         return dx, dw, None, None, None
@@ -572,9 +599,8 @@ class AttentionFn(torch.autograd.Function):
         lib = L.load()
         go = go.contiguous()
         delta = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
-        dq_acc = torch.zeros((B, N, heads * 64), dtype=torch.float32, device=qkv.device)
         dqkv = torch.empty_like(qkv)
-        L.check(lib.tv_attn_bwd(_p(qkv), _p(o), _p(go), _p(lse), _p(delta), _p(dq_acc), _p(dqkv), B, N, heads, ctx.scale, _stream()),
+        L.check(lib.tv_attn_bwd(_p(qkv), _p(o), _p(go), _p(lse), _p(delta), None, _p(dqkv), B, N, heads, ctx.scale, _stream()),
                 "tv_attn_bwd")
         if rope_tab is not None:
             L.check(lib.tv_rope_qk(_p(dqkv), _p(rope_tab), B, N, heads, 1, _stream()), "tv_rope_qk")
