@@ -116,94 +116,111 @@ __device__ __forceinline__ int swz_of(int i) {  // i: row index inside a 16-row 
 
 // Epilogue shared by the tile kernels.  The accumulator layout scatters a row over lanes (8-byte pieces); stored
 // directly the tile costs ~25 % of a K=1728 convolution (measured: K=64 launch 0.44 ms of 1.56 ms).  Instead every wave
-// parks its tile (+bias, bf16) in its own slice of the now idle stage buffers and streams it out row by row, 16 bytes
+// parks its tile (+bias) in its own slice of the now idle stage buffers and streams it out row by row, 16 bytes of bf16
 // per lane: pre-activation store, activation, residual add and the output store are all full-line accesses.
+// The tile is parked in FP32, half of its rows at a time: activation and residual add see the unrounded accumulator and
+// every output is rounded to bf16 exactly once (a bf16 park rounded the pre-activation first: +20-40 % rel-L2 error on
+// whole-model outputs, tools/precision_report.py).
 // m_of_row(r) = output pixel index (b, oy, ox linearised) of wave-tile row r; the caller has synchronised the block.
+template <int WTM, int WTN>
+constexpr int epilogue_lds_bytes(int nwaves) {
+    return nwaves * (WTM >= 32 ? WTM / 2 : WTM) * (WTN * 4 + 16);
+}
+
 template <int WTM, int WTN, class RowMap>
 __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[WTM / 16][WTN / 16], char* smem, int wave, int lane,
                                          int nw0, RowMap m_of_row) {
     constexpr int MF = WTM / 16, NF = WTN / 16;
-    constexpr int ERS = WTN * 2 + 16;          // LDS row stride of the parked tile (16 B pad: bank spread)
-    constexpr int EB = WTM * ERS;              // bytes per wave
+    constexpr int PASSES = MF >= 2 ? 2 : 1, MFP = MF / PASSES, RH = MFP * 16;   // rows per pass
+    static_assert(MF % PASSES == 0, "wave tile rows");
+    constexpr int ERS = WTN * 4 + 16;          // LDS row stride of the parked fp32 rows (16 B pad: bank spread)
+    constexpr int EB = RH * ERS;               // bytes per wave
+    constexpr int CPW = WTN / 8;               // 16-byte OUTPUT chunks (8 channels) per tile row
     const int fi = lane & 15, fq = lane >> 4;
     char* ebuf = smem + wave * EB;
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const int nl = fq * (4 * NF) + j * 4;
-            const int n = nw0 + nl;
-            f32x4 v = acc[i][j];
-            if (p.bias && n < p.N) {
-                const f32x4 bv = *(const f32x4*)(p.bias + n);
-                v += bv;
-            }
-            bf16x4 pv = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *(bf16x4*)(ebuf + (i * 16 + fi) * ERS + nl * 2) = pv;
-        }
-    }
-    // (same wave writes and reads: LDS executes a wave's accesses in order, no barrier needed)
-    constexpr int CPW = WTN / 8;               // 16-byte chunks per tile row
     const int hw = p.h_out * p.w_out;
     const int cq = p.N >> 2;
-#pragma unroll 2
-    for (int idx = lane; idx < WTM * CPW; idx += 64) {
-        const int r = idx / CPW, c8 = idx - r * CPW;
-        const int m = m_of_row(r);
-        const int n = nw0 + c8 * 8;
-        if (m >= p.M || n >= p.N) continue;
-        size_t off;
-        if (p.shuffle == 2) {   // polyphase upsampling conv: grid (H+1) x (W+1), phase (py, px) of cell (sy, sx) is pixel
-            const int sb = m / hw;                      //   (2*sy - py, 2*sx - px) of the [2H, 2W] output; cells on the rim
-            const int rr = m - sb * hw;                 //   have phases that fall outside
-            const int sy = rr / p.w_out, sx = rr - sy * p.w_out;
-            const int qs = n / cq;
-            const int c = n - qs * cq;
-            const int Y = 2 * sy - (qs >> 1), X = 2 * sx - (qs & 1);
-            const int H2 = 2 * (p.h_out - 1), W2 = 2 * (p.w_out - 1);
-            if ((unsigned)Y >= (unsigned)H2 || (unsigned)X >= (unsigned)W2) continue;
-            off = (((size_t)sb * H2 + Y) * W2 + X) * p.ldo + c;
-        } else if (p.shuffle) {
-            const int sb = m / hw;
-            const int rr = m - sb * hw;
-            const int sy = rr / p.w_out, sx = rr - sy * p.w_out;
-            const int qs = n / cq;
-            const int c = n - qs * cq;
-            const size_t pix = ((size_t)sb * (2 * p.h_out) + 2 * sy + (qs >> 1)) * (2 * p.w_out) + 2 * sx + (qs & 1);
-            off = pix * p.ldo + c;
-        } else {
-            off = (size_t)m * p.ldo + n;
-        }
-        bf16x8 z = *(const bf16x8*)(ebuf + r * ERS + c8 * 16);
-        if (p.pre) *(bf16x8*)(p.pre + off) = z;
-        if (p.aux) {  // gradient w.r.t. a pre-activation: (acc + residual gradient) * act'(saved pre-activation)
-            const bf16x8 av = *(const bf16x8*)(p.aux + off);
-            float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (float)z[e];
-            if (p.res) {
-                const bf16x8 rv = *(const bf16x8*)(p.res + off);
+    for (int ps = 0; ps < PASSES; ++ps) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+        for (int ii = 0; ii < MFP; ++ii) {
+            const int i = ps * MFP + ii;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int nl = fq * (4 * NF) + j * 4;
+                const int n = nw0 + nl;
+                f32x4 v = acc[i][j];
+                if (p.bias && n < p.N) {
+                    const f32x4 bv = *(const f32x4*)(p.bias + n);
+                    v += bv;
+                }
+                *(f32x4*)(ebuf + (ii * 16 + fi) * ERS + nl * 4) = v;
             }
+        }
+        // (same wave writes and reads: LDS executes a wave's accesses in order, no barrier needed)
+#pragma unroll 2
+        for (int idx = lane; idx < RH * CPW; idx += 64) {
+            const int rl = idx / CPW, c8 = idx - rl * CPW;
+            const int r = ps * RH + rl;
+            const int m = m_of_row(r);
+            const int n = nw0 + c8 * 8;
+            if (m >= p.M || n >= p.N) continue;
+            size_t off;
+            if (p.shuffle == 2) {   // polyphase upsampling conv: grid (H+1) x (W+1), phase (py, px) of cell (sy, sx) is pixel
+                const int sb = m / hw;                      //   (2*sy - py, 2*sx - px) of the [2H, 2W] output; cells on the rim
+                const int rr = m - sb * hw;                 //   have phases that fall outside
+                const int sy = rr / p.w_out, sx = rr - sy * p.w_out;
+                const int qs = n / cq;
+                const int c = n - qs * cq;
+                const int Y = 2 * sy - (qs >> 1), X = 2 * sx - (qs & 1);
+                const int H2 = 2 * (p.h_out - 1), W2 = 2 * (p.w_out - 1);
+                if ((unsigned)Y >= (unsigned)H2 || (unsigned)X >= (unsigned)W2) continue;
+                off = (((size_t)sb * H2 + Y) * W2 + X) * p.ldo + c;
+            } else if (p.shuffle) {
+                const int sb = m / hw;
+                const int rr = m - sb * hw;
+                const int sy = rr / p.w_out, sx = rr - sy * p.w_out;
+                const int qs = n / cq;
+                const int c = n - qs * cq;
+                const size_t pix = ((size_t)sb * (2 * p.h_out) + 2 * sy + (qs >> 1)) * (2 * p.w_out) + 2 * sx + (qs & 1);
+                off = pix * p.ldo + c;
+            } else {
+                off = (size_t)m * p.ldo + n;
+            }
+            const f32x4 v0 = *(const f32x4*)(ebuf + rl * ERS + c8 * 32);
+            const f32x4 v1 = *(const f32x4*)(ebuf + rl * ERS + c8 * 32 + 16);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            bf16x8 z;
+            if (p.pre) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) z[e] = (bf16)(v[e] * tv_act_grad_rt(p.aux_act, (float)av[e]));
-        } else if (p.act != TV_ACT_NONE || p.res) {
-            float v[8];
+                for (int e = 0; e < 8; ++e) z[e] = (bf16)v[e];
+                *(bf16x8*)(p.pre + off) = z;
+            }
+            if (p.aux) {  // gradient w.r.t. a pre-activation: (acc + residual gradient) * act'(saved pre-activation)
+                const bf16x8 av = *(const bf16x8*)(p.aux + off);
+                if (p.res) {
+                    const bf16x8 rv = *(const bf16x8*)(p.res + off);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = tv_act_rt(p.act, (float)z[e]);
-            if (p.res) {
-                const bf16x8 rv = *(const bf16x8*)(p.res + off);
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                for (int e = 0; e < 8; ++e) v[e] *= tv_act_grad_rt(p.aux_act, (float)av[e]);
+            } else if (p.act != TV_ACT_NONE || p.res) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tv_act_rt(p.act, v[e]);
+                if (p.res) {
+                    const bf16x8 rv = *(const bf16x8*)(p.res + off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) z[e] = (bf16)v[e];
-        }
 #ifdef TV_ABL_NO_STORE
-        if (z[0] == (bf16)123.0f)   // (keeps the value live; practically never true)
+            if (z[0] == (bf16)123.0f)   // (keeps the value live; practically never true)
 #endif
-        *(bf16x8*)(p.out + off) = z;
+            *(bf16x8*)(p.out + off) = z;
+        }
     }
 }
 
@@ -216,7 +233,7 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
 template <int BM, int BN, int NW, int BK, int STAGES>
 constexpr int igemm_min_waves() {
     const int ring = STAGES * (BM + BN) * BK * 2 + (STAGES > 2 ? 1024 : 0);
-    const int epi = BM * (BN * 2 + 16 * (NW == 8 ? 2 : 2));
+    const int epi = BM / 2 * (BN * 4 + 64);   // (fp32 park, half the rows at a time; upper bound over the wave grids)
     const int lds = ring > epi ? ring : epi;
     const int blocks = 160 * 1024 / lds;
     const int w = blocks * NW / 4;
@@ -1125,7 +1142,7 @@ constexpr int LDS_MAX = 160 * 1024;
 template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE>
 int launch_one(const IgemmArgs& a_in, hipStream_t s) {
     constexpr int RING = STAGES * (BM + BN) * BK * 2 + (STAGES > 2 ? 1024 : 0);  // + dummy-DMA scratch slot
-    constexpr int EPI = (WGM * WGN) * (BM / WGM) * ((BN / WGN) * 2 + 16);         // parked output tile (epilogue)
+    constexpr int EPI = epilogue_lds_bytes<BM / WGM, BN / WGN>(WGM * WGN);   // parked output tile (epilogue)
     constexpr int BYTES = RING > EPI ? RING : EPI;
     if constexpr (BYTES > LDS_MAX) {
         return -1;
@@ -1194,7 +1211,7 @@ template <int BM, int BN, int WGM, int WGN, int BST>
 int launch_halo_one(const IgemmArgs& a_in, hipStream_t s) {
     constexpr int NW = WGM * WGN, HP = (BM / 16 + 2) * 18;
     constexpr int RING = 2 * (((HP * 8 + 63) / 64) * 1024) + BST * BN * 64 * 2;
-    constexpr int EPI = NW * (BM / WGM) * ((BN / WGN) * 2 + 16);
+    constexpr int EPI = epilogue_lds_bytes<BM / WGM, BN / WGN>(NW);
     constexpr int BYTES = RING > EPI ? RING : EPI;
     if constexpr (BYTES > LDS_MAX) {
         return -1;
