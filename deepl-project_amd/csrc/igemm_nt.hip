@@ -63,6 +63,9 @@ struct IgemmArgs {
 #ifndef TV_GENERIC_BURST
 #define TV_GENERIC_BURST 1    // same for the generic 256x256 tile (A/B on the 768-channel linear layers: +2-5 %)
 #endif
+#ifndef TV_PIPE_ALL_MAX
+#define TV_PIPE_ALL_MAX 80   // fragment registers (both halves) up to which the generic kernel runs the pipelined loop
+#endif
 #ifndef TV_DMA_STAGGER
 #define TV_DMA_STAGGER 0    // two code copies with shifted DMA slots for waves 0-3 / 4-7: measured -3 % (register pressure)
 #endif
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
     // Fragment reads are software-pipelined against the MFMAs: where the registers allow (<= 80 fragment VGPRs) ALL reads
     // of the K-step (both 32-deep halves) are issued up front, so the second half's ds_read_b128s fly under the first
     // half's MFMAs instead of exposing their latency a second time; the 256x256 tile keeps one half in flight at a time.
-    constexpr bool PIPE_ALL = (MF + NF) * 4 * (BK / 32) <= 80;
+    constexpr bool PIPE_ALL = (MF + NF) * 4 * (BK / 32) <= TV_PIPE_ALL_MAX;
     // `nbase` != nullptr: the DMA pieces of the K-step being staged go out between the MFMAs, one every GAP of them
     constexpr int NMF = MF * NF * (BK / 32), GAP = NMF / NI > 0 ? NMF / NI : 1;
     auto compute = [&](const char* sbase, char* nbase, auto issue_c) {
