@@ -1182,26 +1182,46 @@ int launch_big(const IgemmArgs& a, int bm, int stages, hipStream_t s) {
     }
 }
 
+// Tile choice by a wave-quantisation model: time ~ rounds over the chip's block slots x work of one tile / efficiency
+// of the tile shape.  256x256 and 256x192 hold one block per CU, 128x128 two; the 128-row tile pays ~15 % in L2->LDS
+// traffic per FLOP.  (Library GEMMs at these shapes run 1000-1290 TFLOP/s, tools/probes/mm_bench.py; the fixed rule
+// "256 wide when >= 512 tiles, else 128" left M = 16 K, N = 1536 layers on 128x128 tiles at 865.)
+// Returns BN (256 / 192 / 128) and sets bm; tuning hooks override.
+int pick_tile(long long M, int N, bool allow256, bool allow192_256rows, int* bm) {
+    const long long m256 = (M + 255) / 256, m128 = (M + 127) / 128;
+    double best = 1e30;
+    int bn = 128;
+    *bm = 128;
+    auto consider = [&](int cbn, int cbm, long long tiles, double slots, double eff) {
+        const double rounds = (double)((long long)((tiles + slots - 1) / slots));
+        const double t = rounds * (double)cbm * cbn * (slots / 256.0) / eff;
+        if (t < best) { best = t; bn = cbn; *bm = cbm; }
+    };
+    consider(128, 128, m128 * ((N + 127) / 128), 512.0, 0.85);
+    if (N % 192 == 0 && allow192_256rows) consider(192, 256, m256 * (N / 192), 256.0, 0.97);
+    if (N % 192 == 0 && N % 128 != 0) consider(192, 128, m128 * (N / 192), 256.0, 0.80);
+    if (N % 256 == 0 && allow256) consider(256, 256, m256 * (N / 256), 256.0, 1.0);
+    return bn;
+}
+
 template <int BK, int MODE>
 int launch_mode(IgemmArgs& a, hipStream_t s) {
     const int N = a.N;
     const int stages = g_cfg_stages ? g_cfg_stages : 2;
-    const long long m256 = (a.M + 255) / 256;
-    // Tile heuristic (tools/gemm_sweep.py, mb 64): 256x256 tiles (8 waves, 128x64 per wave: half the LDS bytes per
-    // MFMA) win 5-15 % where c_out % 256 == 0 and the grid still has >= 512 blocks; 256-row tiles help the N=192
-    // convolutions a little when M is huge; everything else runs 128-row tiles at 2-3 blocks per CU.
-    if (N % 192 == 0 && N % 128 != 0) {
-        a.tiles_n = N / 192;
-        const int bm = g_cfg_bm ? g_cfg_bm : (m256 * a.tiles_n >= 1024 ? 256 : 128);
-        return launch_big<192, BK, MODE>(a, bm, stages, s);
-    }
-    const bool want256 = g_cfg_bn ? (g_cfg_bn == 256) : (g_cfg_bm == 0 && m256 * (N / 256) >= 512);
-    if (want256 && N % 256 == 0) {
-        a.tiles_n = N / 256;
-        return launch_big<256, BK, MODE>(a, g_cfg_bm ? g_cfg_bm : 256, stages, s);
-    }
-    const int bm = g_cfg_bm ? g_cfg_bm : 128;
     if (N > 64) {
+        int bm = 128;
+        int bn = pick_tile(a.M, N, true, true, &bm);
+        if (g_cfg_bn == 256 && N % 256 == 0) { bn = 256; bm = 256; }
+        else if (g_cfg_bn == 128) { bn = (N % 192 == 0 && N % 128 != 0) ? 192 : 128; bm = 128; }
+        if (g_cfg_bm) bm = g_cfg_bm;
+        if (bn == 256) {
+            a.tiles_n = N / 256;
+            return launch_big<256, BK, MODE>(a, bm, stages, s);
+        }
+        if (bn == 192) {
+            a.tiles_n = N / 192;
+            return launch_big<192, BK, MODE>(a, bm, stages, s);
+        }
         a.tiles_n = (N + 127) / 128;
         return launch_big<128, BK, MODE>(a, bm, stages, s);
     }
@@ -1247,22 +1267,27 @@ int launch_halo(IgemmArgs& a, hipStream_t s) {
     if (a.h_in != a.h_out || a.w_in != a.w_out || a.w_out % 16 != 0 || a.h_out % 8 != 0) return -1;
     const int N = a.N;
     const bool h16 = a.h_out % 16 == 0;
-    const long long m256 = (a.M + 255) / 256;
-    if (N % 192 == 0 && N % 128 != 0) {
+    int bm = 128;
+    // (256x192 halo tiles with several N tiles run the 2-deep weight ring, which recomputes its DMA offsets: slower than
+    //  128x128 there -- only the one-N-tile case takes 192 by choice)
+    int bn = pick_tile(a.M, N, h16, h16 && (N == 192 || N % 128 != 0), &bm);
+    if (g_cfg_bn == 256 && N % 256 == 0 && h16) { bn = 256; bm = 256; }
+    else if (g_cfg_bn == 128) { bn = (N % 192 == 0 && N % 128 != 0) ? 192 : 128; bm = 128; }
+    if (g_cfg_bm) bm = g_cfg_bm;
+    if (bm == 256 && !h16) bm = 128;
+    if (bn == 192) {
         a.tiles_n = N / 192;
-        const int bm = g_cfg_bm ? g_cfg_bm : (m256 * a.tiles_n >= 1024 ? 256 : 128);
         // weight ring 3 deep only where measured faster (one N tile: res192@256/@128); 2 everywhere else
-        if (bm == 256 && h16 && g_halo_w4) return launch_halo_ring<256, 192, 2, 2>(a, (g_halo_ring == 3 && a.tiles_n == 1) || g_halo_ring == 4 ? 3 : 2, s);
-        if (bm == 256 && h16) return launch_halo_ring<256, 192, 4, 2>(a, (g_halo_ring == 3 && a.tiles_n == 1) || g_halo_ring == 4 ? 3 : 2, s);
+        if (bm == 256 && g_halo_w4) return launch_halo_ring<256, 192, 2, 2>(a, (g_halo_ring == 3 && a.tiles_n == 1) || g_halo_ring == 4 ? 3 : 2, s);
+        if (bm == 256) return launch_halo_ring<256, 192, 4, 2>(a, (g_halo_ring == 3 && a.tiles_n == 1) || g_halo_ring == 4 ? 3 : 2, s);
         return launch_halo_ring<128, 192, 2, 2>(a, g_halo_ring == 4 ? 3 : 2, s);
     }
-    const bool want256 = g_cfg_bn ? (g_cfg_bn == 256) : (g_cfg_bm == 0 && m256 * (N / 256) >= 512);
-    if (want256 && N % 256 == 0 && h16) {
+    if (bn == 256 && bm == 256) {
         a.tiles_n = N / 256;
         return launch_halo_ring<256, 256, 2, 4>(a, 2, s);
     }
     a.tiles_n = (N + 127) / 128;
-    if (g_cfg_bm == 256 && h16) return launch_halo_ring<256, 128, 4, 2>(a, g_halo_ring == 4 ? 3 : 2, s);
+    if (bm == 256) return launch_halo_ring<256, 128, 4, 2>(a, g_halo_ring == 4 ? 3 : 2, s);
     return launch_halo_ring<128, 128, 2, 2>(a, g_halo_ring == 4 ? 3 : 2, s);
 }
 
