@@ -11,3 +11,7 @@ for (M,K,N) in [(65536,768,3072),(65536,3072,768),(65536,768,2304),(16384,1536,6
     a=torch.randn(M,K,device=dev).to(torch.bfloat16); w=torch.randn(N,K,device=dev).to(torch.bfloat16)
     t=tm(lambda: torch.nn.functional.linear(a,w))
     print(f"M={M:8d} K={K:5d} N={N:5d}: {t:7.3f} ms {2*M*K*N/t/1e9:7.0f} TF/s")
+for (M,K,N) in [(8192,8192,8192),(16384,8192,8192),(4194304,1728,192)]:
+    a=torch.randn(M,K,device=dev).to(torch.bfloat16); w=torch.randn(N,K,device=dev).to(torch.bfloat16)
+    t=tm(lambda: torch.nn.functional.linear(a,w))
+    print(f"M={M:8d} K={K:5d} N={N:5d}: {t:7.3f} ms {2*M*K*N/t/1e9:7.0f} TF/s")
