@@ -428,6 +428,7 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
 int g_wgrad_bkp = 0;     // 0 = heuristic (64), else 32 / 64 pixels per K-step
 int g_wgrad_blocks = 0;  // 0 = heuristic: target number of blocks for the split-K choice
 int g_wgrad_tile256 = 0; // 0 = heuristic (linear layers only), 1 = always when both channel counts are multiples of 256, 2 = never
+int g_wgrad_prefer192 = 0;   // experiment: 192-wide tiles wherever the channel count divides
 int g_wgrad_xcd = 1;     // 1 = tiles of one pixel chunk share an XCD (block order in the kernel)
 int g_wgrad_generic = 0; // 1 = never use the FAST staging path (A/B)
 int g_wgrad_waves = 0;   // 0 = heuristic (8 waves for the 192-wide co tile), 4 / 8 = force
@@ -464,7 +465,7 @@ int launch_s(const WgradArgs& a, dim3 grid, hipStream_t s) {
 }
 
 template <int TG, int TX>
-int launch(const WgradArgs& a0, hipStream_t s, bool plan_only) {
+int launch(const WgradArgs& a0, hipStream_t s, bool plan_only, double* t_model = nullptr) {
     WgradArgs a = a0;
     const int bkp = g_wgrad_bkp ? g_wgrad_bkp : (TG == 192 ? 64 : 32);   // measured: 64 pays only where 8 waves share the tile
     const int tiles_co = (a.c_out + TG - 1) / TG;
@@ -476,15 +477,18 @@ int launch(const WgradArgs& a0, hipStream_t s, bool plan_only) {
     const bool w8 = g_wgrad_waves != 4 && (TG >= 192 || g_wgrad_waves == 8) && TX >= 128;
     const int per_cu = w8 ? 1 : (((TG / 32) * (TX / 32) <= 16) ? 3 : 2);
     const double slots = 256.0 * per_cu;
-    const double t_px = 2.0 * TG * TX * slots / 750e12;                // seconds per pixel for one resident block
+    // sustained rate of the tile shape (calibrated on the linear layers: 256x256 ~10 % over the pipelined 192-wide tiles,
+    // those ~13 % over 128x128) -- only the ratios matter, for comparing candidate tiles
+    const double rate = (TG == 256 && TX == 256) ? 990e12 : ((TG >= 192 && TX >= 192) ? 900e12 : ((TG >= 192 || TX >= 192) ? 850e12 : 800e12));
+    const double t_px = 2.0 * TG * TX * slots / rate;                  // seconds per pixel for one resident block
     const double tile_bytes = 4.0 * TG * TX;
     long long split = 1;
     bool xcd = false;
+    double best = 1e30;
     if (g_wgrad_blocks) {
         split = (g_wgrad_blocks + base - 1) / base;
         xcd = g_wgrad_xcd != 0;
     } else {
-        double best = 1e30;
         const long long smax = a.M / 512 > 0 ? a.M / 512 : 1;
         for (long long sp = 1; sp <= smax && sp <= 4096; ++sp) {
             const double rounds = (double)((long long)((base * sp + slots - 1) / slots));
@@ -509,6 +513,7 @@ int launch(const WgradArgs& a0, hipStream_t s, bool plan_only) {
     a.chunk_px = (int)chunk;
     const int ny = (int)((a.M + chunk - 1) / chunk);
     a.plain = (ny == 1) ? 1 : 0;
+    if (t_model) *t_model = best;
     if (plan_only) return 100 + a.plain;   // (distinct from the TV_ERR_* codes)
     a.base = (int)base;
     a.ny = ny;
@@ -546,7 +551,8 @@ extern "C" int tv_set_wgrad_stages(int stages) {   // 0 = heuristic, 2 / 3; +10:
 
 extern "C" int tv_set_wgrad_config(int bkp, int waves, int blocks) {
     g_wgrad_generic = (blocks == -1) ? 1 : 0;
-    g_wgrad_tile256 = (blocks == -2) ? 1 : (blocks == -3 ? 2 : 0);
+    g_wgrad_tile256 = (blocks == -2) ? 1 : ((blocks == -3 || blocks == -4) ? 2 : 0);
+    g_wgrad_prefer192 = (blocks == -4) ? 1 : 0;
     if (blocks < 0) blocks = 0;
     g_wgrad_bkp = bkp;
     g_wgrad_waves = waves;
@@ -583,14 +589,26 @@ static int wgrad_impl(const tv_conv_desc* d, const void* x, const void* gy, floa
     a.xcd_order = 0; a.base = 1; a.ny = 1;
     hipStream_t s = (hipStream_t)stream;
     // 256x256 tiles (8 waves, 128x64 per wave): +5..20 % on linear layers, -9 % on 9-tap convolutions (gemm_sweep, mb 64)
-    if ((g_wgrad_tile256 == 1 || (g_wgrad_tile256 == 0 && d->kh * d->kw == 1)) && d->c_out % 256 == 0 && d->c_in % 256 == 0) {
+    // single-tap layers: 256x256 or 192x192 tiles by the modelled time of their best split (wave quantisation decides:
+    // 1536 -> 6144 at 16 K pixels is exactly 256 tiles of 192x192 with plain stores, while qkv widths fill better at 256)
+    bool use256 = (g_wgrad_tile256 == 1 || (g_wgrad_tile256 == 0 && d->kh * d->kw == 1)) && d->c_out % 256 == 0 && d->c_in % 256 == 0;
+    bool both192 = d->kh * d->kw == 1 && d->c_out % 192 == 0 && d->c_in % 192 == 0 && g_wgrad_tile256 == 0 && !g_wgrad_blocks;
+    if (both192) {
+        double t192 = 1e30, t_alt = 1e30;
+        launch<192, 192>(a, s, true, &t192);
+        if (use256) launch<256, 256>(a, s, true, &t_alt);
+        else launch<128, 128>(a, s, true, &t_alt);
+        if (t192 < t_alt) use256 = false;
+        else both192 = false;
+    }
+    if (use256) {
         const int r = launch<256, 256>(a, s, plan_only);
         if (plan_only) return r;
         TV_CHECK_LAUNCH("tv_wgrad_tn");
         return TV_OK;
     }
-    const bool g192 = (d->c_out % 192 == 0) && (d->c_out % 128 != 0);
-    const bool x192 = (d->c_in % 192 == 0) && (d->c_in % 128 != 0);
+    const bool g192 = (d->c_out % 192 == 0) && (d->c_out % 128 != 0 || g_wgrad_prefer192 || both192);
+    const bool x192 = (d->c_in % 192 == 0) && (d->c_in % 128 != 0 || g_wgrad_prefer192 || both192);
     const bool g64 = d->c_out <= 64, x64 = d->c_in <= 64;
     int r;
     if (g192 && x192) r = launch<192, 192>(a, s, plan_only);
