@@ -123,7 +123,7 @@ __device__ __forceinline__ int swz_of(int i) {  // i: row index inside a 16-row 
 // per lane: pre-activation store, activation, residual add and the output store are all full-line accesses.
 // The tile is parked in FP32, half of its rows at a time: activation and residual add see the unrounded accumulator and
 // every output is rounded to bf16 exactly once (a bf16 park rounded the pre-activation first: +20-40 % rel-L2 error on
-// whole-model outputs, tools/precision_report.py).
+// whole-model outputs, tests/precision_report.py).
 // m_of_row(r) = output pixel index (b, oy, ox linearised) of wave-tile row r; the caller has synchronised the block.
 template <int WTM, int WTN>
 constexpr int epilogue_lds_bytes(int nwaves) {

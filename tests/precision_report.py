@@ -1,6 +1,6 @@
 """Full-tensor error of the HIP path against the fp32 CPU oracle (run on the GPU box).
 
-    python tools/precision_report.py [micro|tiny] ...
+    python tests/precision_report.py [micro|tiny] ...
 
 Prints rel-L2 errors of recon / mu / logvar and per-stage encoder/decoder activations, so that
 precision regressions can be localised.  Diagnostic only (imports oracle/ as the checker).

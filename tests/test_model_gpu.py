@@ -11,7 +11,7 @@ The HIP path stores activations in bf16 (fp32 accumulate).  Tolerances, all rela
     bf16 tier -- its bf16-autocast forward deviates from its fp32 forward by 2.0e-2 / 1.2e-2
     (micro recon / mu) and 2.5-3.2e-2 / 1.3e-2 (tiny, BASELINE config 1), numbers stored in the
     goldens.  We require  err <= max(1e-2, 1.25 * that deviation)  and measure 1.7e-2 / 1.0e-2
-    (micro) and 2.7e-2 / 1.2e-2 (tiny) -- see tools/precision_report.py.
+    (micro) and 2.7e-2 / 1.2e-2 (tiny) -- see tests/precision_report.py.
 Activations are bit-reproducible run to run (GroupNorm reductions are ordered, attention has no
 atomics); weight gradients are summed with fp32 atomics (order noise ~1e-7), so equalities between
 runs are checked to tolerance.
