@@ -197,6 +197,26 @@ def test_micro_model_nonsquare_against_oracle():
     assert float(np.median(norms)) < 3e-2 and max(norms) < 0.2
 
 
+def test_f8_style_config_against_oracle():
+    """Compression ratio 8 (three downsamples, four stages: the layout of large_f8d16, R/transvae/models/transvae.py:107-153)
+    on a small config against the fp32 oracle."""
+    from transvae import TransVAE
+    cfg = dict(depths=[1, 1, 1, 1], base_dims=[32, 64, 64, 128], mlp_ratio=1.0, head_dim=64)
+    torch.manual_seed(3)
+    m = TransVAE(config=dict(cfg), variant="micro8", compression_ratio=8, latent_dim=4)
+    sd = filler.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(2, 3, 64, 64, generator=g)
+    eps = torch.randn(2, 4, 8, 8, generator=g)
+    with torch.no_grad():
+        recon, mu, logvar = m(x.to(DEV), eps=eps.to(DEV))
+    r_ref, mu_ref, lv_ref = O.forward(x, sd, cfg, eps)
+    assert mu.shape == (2, 4, 8, 8) and recon.shape == x.shape
+    assert l2rel(recon, r_ref) < 2.5e-2 and l2rel(mu, mu_ref) < 1.5e-2 and l2rel(logvar, lv_ref) < 2e-2
+
+
 def test_micro_model_tuple_forward_uses_global_rng_and_clamp_variant():
     m = micro_model()
     x = filler.rand_input("micro.x", (2, 3, 64, 64)).to(DEV)
