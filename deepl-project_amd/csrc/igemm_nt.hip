@@ -1212,6 +1212,7 @@ int launch_mode(IgemmArgs& a, hipStream_t s) {
         int bm = 128;
         int bn = pick_tile(a.M, N, true, true, &bm);
         if (g_cfg_bn == 256 && N % 256 == 0) { bn = 256; bm = 256; }
+        else if (g_cfg_bn == 192 && N % 192 == 0) { bn = 192; bm = 256; }
         else if (g_cfg_bn == 128) { bn = (N % 192 == 0 && N % 128 != 0) ? 192 : 128; bm = 128; }
         if (g_cfg_bm) bm = g_cfg_bm;
         if (bn == 256) {
