@@ -267,7 +267,11 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const bool do_bias = (p.dbias != nullptr) && tap == 0 && ci_tile == 0 && wn == 0;
+    // bias gradient: the blocks that own (tap 0, ci tile 0) run one extra MFMA per co fragment against an all-ones operand.
+    // The NWN waves of a row share the same gy fragments, so fragment i goes to wave (i mod NWN): loading ONE wave with all
+    // MF of them (+33 % MFMAs on the 192x192 tile) made it, and with it the block and the launch, wait for that wave.
+    const bool do_bias = (p.dbias != nullptr) && tap == 0 && ci_tile == 0;
+    auto bias_mine = [&](int i) { return do_bias && (i % NWN) == wn; };
     const bf16 one = (bf16)1.0f;
     const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
@@ -304,11 +308,9 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
 #pragma unroll
                 for (int j = 0; j < H; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], join(blo[j], bhi[j]), acc[i][j], 0, 0, 0);
-            if (do_bias) {
 #pragma unroll
-                for (int i = 0; i < MF; ++i)
-                    accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
-            }
+            for (int i = 0; i < MF; ++i)
+                if (bias_mine(i)) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
             lds_wait_all();
 #pragma unroll
             for (int i = 0; i < MF; ++i)
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
 #pragma unroll
                 for (int j = 0; j < NF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, join(blo[j], bhi[j]), acc[i][j], 0, 0, 0);
-                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[i], 0, 0, 0);
+                if (bias_mine(i)) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[i], 0, 0, 0);
             }
         };
         const int U = nsteps * KH;
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
                     else atomicAdd(rowp + ci, acc[i][j][r]);
                 }
             }
-            if (do_bias && (lane & 15) == 0) {
+            if (bias_mine(i) && (lane & 15) == 0) {
                 if (p.plain) p.dbias[co] = accb[i][r];
                 else atomicAdd(p.dbias + co, accb[i][r]);
             }
