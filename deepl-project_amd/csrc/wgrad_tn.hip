@@ -267,11 +267,15 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // bias gradient: the blocks that own (tap 0, ci tile 0) run one extra MFMA per co fragment against an all-ones operand.
-    // The NWN waves of a row share the same gy fragments, so fragment i goes to wave (i mod NWN): loading ONE wave with all
-    // MF of them (+33 % MFMAs on the 192x192 tile) made it, and with it the block and the launch, wait for that wave.
-    const bool do_bias = (p.dbias != nullptr) && tap == 0 && ci_tile == 0;
-    auto bias_mine = [&](int i) { return do_bias && (i % NWN) == wn; };
+    // bias gradient: one extra MFMA per co fragment against an all-ones operand.  Every wave of a row (and every tap's
+    // block) holds the same gy fragments, so the fragments are dealt out: loading ONE wave of the tap-0 block with all MF
+    // of them (+33 % MFMAs on the 192x192 tile) made it, and with it the block and the launch, wait for that wave.
+    // Fragment f = wm*MF + i of this co tile is summed by the wave in slot f mod (taps*NWN), slot = tap + taps*wn, of the
+    // blocks with ci tile 0: every tap's block carries its share (at most one extra MFMA per wave on the 3x3 layers).
+    // (A single-branch form -- one owned fragment per wave, selected outside the fragment loop -- measured slower.)
+    const bool do_bias = (p.dbias != nullptr) && ci_tile == 0;
+    const int bias_slots = taps * NWN, bias_slot = tap + taps * wn;
+    auto bias_mine = [&](int i) { return do_bias && ((wm * MF + i) % bias_slots) == bias_slot; };
     const bf16 one = (bf16)1.0f;
     const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
