@@ -48,8 +48,8 @@ const void* tv_zero_page();  // >= 4 KiB of device zeros (source for padded LDS-
 
 __device__ __forceinline__ float tv_fast_exp(float x) { return __expf(x); }
 
-// returns erf(|x|) pieces: e = exp(-x^2), poly*e = 1-erf(|x|)
-__device__ __forceinline__ float tv_erf(float x) {
+// erf(x) with e = exp(-x^2) handed back (the Gaussian the GELU gradient needs as well)
+__device__ __forceinline__ float tv_erf_e(float x, float& e) {
     const float ax = fabsf(x);
     const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
@@ -57,18 +57,23 @@ __device__ __forceinline__ float tv_erf(float x) {
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
     p *= t;
-    const float e = tv_fast_exp(-ax * ax);
+    e = tv_fast_exp(-ax * ax);
     const float r = fmaf(-p, e, 1.0f);
     return copysignf(r, x);
+}
+__device__ __forceinline__ float tv_erf(float x) {
+    float e;
+    return tv_erf_e(x, e);
 }
 
 __device__ __forceinline__ float tv_gelu(float z) { return 0.5f * z * (1.0f + tv_erf(z * 0.70710678118654752f)); }
 
-// d/dz gelu(z) = Phi(z) + z*phi(z)
+// d/dz gelu(z) = Phi(z) + z*phi(z);  phi(z) = exp(-z^2/2)/sqrt(2 pi) is the exp(-x^2) of the erf at x = z/sqrt(2): one
+// exponential per element (the activation-gradient epilogues are VALU-bound on exactly this arithmetic)
 __device__ __forceinline__ float tv_gelu_grad(float z) {
-    const float cdf = 0.5f * (1.0f + tv_erf(z * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * tv_fast_exp(-0.5f * z * z);
-    return fmaf(z, pdf, cdf);
+    float e;
+    const float cdf = fmaf(0.5f, tv_erf_e(z * 0.70710678118654752f, e), 0.5f);
+    return fmaf(z * 0.3989422804014327f, e, cdf);
 }
 
 __device__ __forceinline__ float tv_sigmoid(float z) { return __frcp_rn(1.0f + tv_fast_exp(-z)); }

@@ -130,7 +130,14 @@ constexpr int epilogue_lds_bytes(int nwaves) {
     return nwaves * (WTM >= 32 ? WTM / 2 : WTM) * (WTN * 4 + 16);
 }
 
-template <int WTM, int WTN, class RowMap>
+// EPI = 0: every option decided at run time inside the row loop (shuffled stores, saved pre-activation, activation,
+//          activation gradient, ...).
+// EPI = 1: plain row store + residual add, no activation (ffn_out / proj / ResBlock conv2 and every data gradient that
+//          adds a second gradient of the same tensor).  ALL of a pass's residual loads are issued before the tile is
+//          parked, so their latency runs under the LDS round trip instead of once per pair of row chunks: +3...37 % on
+//          these layers (tools/probes/ab_epilogue.py).  The same treatment of the activation-gradient epilogue measured
+//          -13...+5 % (its erf / exp arithmetic is the cost there, and the unrolled form is large): it stays on EPI 0.
+template <int WTM, int WTN, int EPI, class RowMap>
 __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[WTM / 16][WTN / 16], char* smem, int wave, int lane,
                                          int nw0, RowMap m_of_row) {
     constexpr int MF = WTM / 16, NF = WTN / 16;
@@ -145,6 +152,23 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
     const int cq = p.N >> 2;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
+        constexpr int ITER = (RH * CPW + 63) / 64;
+        [[maybe_unused]] unsigned eoff[EPI ? ITER : 1];   // in 16-byte units (host checks the range); ~0u: outside the tensor
+        [[maybe_unused]] bf16x8 erv[EPI ? ITER : 1];
+        if constexpr (EPI != 0) {
+#pragma unroll
+            for (int k = 0; k < ITER; ++k) {
+                const int idx = lane + 64 * k;
+                const int rl = idx / CPW, c8 = idx - rl * CPW;
+                const int m = m_of_row(ps * RH + rl);
+                const int n = nw0 + c8 * 8;
+                const bool ok = idx < RH * CPW && m < p.M && n < p.N;
+                eoff[k] = ok ? (unsigned)(((long long)m * p.ldo + n) >> 3) : ~0u;
+            }
+#pragma unroll
+            for (int k = 0; k < ITER; ++k)
+                if (eoff[k] != ~0u) erv[k] = *(const bf16x8*)(p.res + (size_t)eoff[k] * 8);
+        }
 #pragma unroll
         for (int ii = 0; ii < MFP; ++ii) {
             const int i = ps * MFP + ii;
@@ -159,6 +183,24 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
                 }
                 *(f32x4*)(ebuf + (ii * 16 + fi) * ERS + nl * 4) = v;
             }
+        }
+        if constexpr (EPI != 0) {
+#pragma unroll
+            for (int k = 0; k < ITER; ++k) {
+                if (eoff[k] == ~0u) continue;
+                const int idx = lane + 64 * k;
+                const int rl = idx / CPW, c8 = idx - rl * CPW;
+                const f32x4 v0 = *(const f32x4*)(ebuf + rl * ERS + c8 * 32);
+                const f32x4 v1 = *(const f32x4*)(ebuf + rl * ERS + c8 * 32 + 16);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)erv[k][e];
+                bf16x8 z;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = (bf16)v[e];
+                *(bf16x8*)(p.out + (size_t)eoff[k] * 8) = z;
+            }
+            continue;
         }
         // (same wave writes and reads: LDS executes a wave's accesses in order, no barrier needed)
 #pragma unroll 2
@@ -243,7 +285,7 @@ constexpr int igemm_min_waves() {
     return w >= 2 ? 2 : 1;
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE>
+template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE, int EPI>
 __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, BK, STAGES>())) void igemm_nt_kernel(const IgemmArgs p) {
     constexpr bool DMA = MODE != 0, BUF = MODE == 2;
     constexpr int NW = WGM * WGN;
@@ -699,7 +741,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
     TV_T(5);
     __syncthreads();                           // every wave is done reading the stage buffers
     const int mrow0 = m0 + wm * WTM;
-    epilogue<WTM, WTN>(p, acc, smem, wave, lane, n0 + wn * WTN, [&](int r) { return mrow0 + r; });
+    epilogue<WTM, WTN, EPI>(p, acc, smem, wave, lane, n0 + wn * WTN, [&](int r) { return mrow0 + r; });
     TV_T(6);
     TV_PROBE_DUMP(wave, lane);
 }
@@ -718,7 +760,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 //   16-pixel run of a halo row is conflict-free for ds_read_b128 whatever the tap shift.
 //   Zero padding: halo pixels outside the image use an out-of-range buffer offset (the DMA writes zeros).
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int BST>
+template <int BM, int BN, int WGM, int WGN, int BST, int EPI>
 __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const IgemmArgs p) {
     constexpr int BK = 64, NW = WGM * WGN, TW = 16, TH = BM / TW, HWD = TW + 2, HP = (TH + 2) * HWD;
     constexpr int A_PIECES = (HP * 8 + 63) / 64;             // 1 KiB DMA pieces per halo chunk (8 pixels each)
@@ -1124,7 +1166,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
     __syncthreads();
     // wave-tile row r -> output pixel: fragment row i = r / 16 is tile row wm*MF + i, r % 16 the column
     const int pix0 = (b * p.h_out + y0 + wm * MF) * p.w_out + x0;
-    epilogue<WTM, WTN>(p, acc, smem, wave, lane, n0 + wn * WTN, [&](int r) { return pix0 + (r >> 4) * p.w_out + (r & 15); });
+    epilogue<WTM, WTN, EPI>(p, acc, smem, wave, lane, n0 + wn * WTN, [&](int r) { return pix0 + (r >> 4) * p.w_out + (r & 15); });
     TV_T(6);
     TV_PROBE_DUMP(wave, lane);
 }
@@ -1142,6 +1184,14 @@ bool g_use_halo = true;  // 3x3 stride-1 convolutions through conv3x3_halo_kerne
 
 constexpr int LDS_MAX = 160 * 1024;
 
+bool g_epi_modes = true;   // compile-time epilogue forms (tv_set_igemm_epilogue(0): the generic one everywhere, for A/B timing)
+
+// which epilogue form a call takes (see epilogue<>): 1 = residual add only, 0 = everything else
+int epilogue_mode(const IgemmArgs& a) {
+    if (!g_epi_modes || a.shuffle || a.pre || a.aux || ((long long)a.M * a.ldo >> 3) >= 0xffffffffll) return 0;
+    return (a.res && a.act == TV_ACT_NONE) ? 1 : 0;
+}
+
 template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE>
 int launch_one(const IgemmArgs& a_in, hipStream_t s) {
     constexpr int RING = STAGES * (BM + BN) * BK * 2 + (STAGES > 2 ? 1024 : 0);  // + dummy-DMA scratch slot
@@ -1155,13 +1205,21 @@ int launch_one(const IgemmArgs& a_in, hipStream_t s) {
         a.tiles_m = tiles_m;
         a.xcd_order = (g_xcd_order && a.tiles_n > 1) ? 1 : 0;
         dim3 grid((unsigned)(a.xcd_order ? 8 * a.tiles_n * ((tiles_m + 7) / 8) : tiles_m * a.tiles_n)), block(WGM * WGN * 64);
-        static bool attr_done = false;
-        if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in
-            (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-            attr_done = true;
+        auto go = [&](auto epi) {
+            constexpr int EPI_MODE = decltype(epi)::value;
+            static bool attr_done = false;
+            if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in
+                (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE, EPI_MODE>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE, EPI_MODE>), grid, block, BYTES, s, a);
+        };
+        const int epi = epilogue_mode(a);
+        if constexpr (MODE == 2 && BM * BN >= 128 * 128) {   // (the bring-up modes and the narrow tiles keep the one generic epilogue)
+            if (epi == 1) { go(std::integral_constant<int, 1>{}); return 0; }
         }
-        hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE>), grid, block, BYTES, s, a);
+        go(std::integral_constant<int, 0>{});
         return 0;
     }
 }
@@ -1245,12 +1303,18 @@ int launch_halo_one(const IgemmArgs& a_in, hipStream_t s) {
         a.tiles_m = tiles_m;
         a.xcd_order = (g_xcd_order && a.tiles_n > 1) ? 1 : 0;
         dim3 grid((unsigned)(a.xcd_order ? 8 * a.tiles_n * ((tiles_m + 7) / 8) : tiles_m * a.tiles_n)), block(NW * 64);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, BN, WGM, WGN, BST>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-            attr_done = true;
-        }
-        hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WGM, WGN, BST>), grid, block, BYTES, s, a);
+        auto go = [&](auto epi) {
+            constexpr int EPI_MODE = decltype(epi)::value;
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, BN, WGM, WGN, BST, EPI_MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WGM, WGN, BST, EPI_MODE>), grid, block, BYTES, s, a);
+        };
+        const int epi = epilogue_mode(a);
+        if (epi == 1) go(std::integral_constant<int, 1>{});
+        else go(std::integral_constant<int, 0>{});
         return 0;
     }
 }
@@ -1314,6 +1378,11 @@ extern "C" int tv_set_igemm_halo(int on) {   // 0: 3x3 stride-1 convolutions thr
     on %= 10;
     g_use_halo = on != 0;   // 1: heuristic ring depth, 2: ring 2 everywhere, 4: ring 3 wherever it fits
     g_halo_ring = (on == 2) ? 2 : (on == 4 ? 4 : 3);
+    return 0;
+}
+
+extern "C" int tv_set_igemm_epilogue(int on) {   // 0: generic (run-time) epilogue everywhere, for A/B timing and tests
+    g_epi_modes = on != 0;
     return 0;
 }
 
