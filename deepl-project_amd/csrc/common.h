@@ -45,6 +45,8 @@ const void* tv_zero_page();  // >= 4 KiB of device zeros (source for padded LDS-
 #define TV_ACT_NONE 0
 #define TV_ACT_GELU 1
 #define TV_ACT_SILU 2
+#define TV_ACT_DERIV 3        // (aux_act only) the saved tensor already holds act'(pre-activation)
+#define TV_ACT_SAVE_DERIV 16  // (flag on desc.act) pre_act receives act'(pre-activation) instead of the pre-activation
 
 __device__ __forceinline__ float tv_fast_exp(float x) { return __expf(x); }
 
@@ -98,6 +100,22 @@ __device__ __forceinline__ float tv_act_grad_rt(int act, float z) {
     if (act == TV_ACT_GELU) return tv_gelu_grad(z);
     if (act == TV_ACT_SILU) return tv_silu_grad(z);
     return 1.0f;
+}
+// act(z) with its derivative from the same erf / exponential / sigmoid (forward epilogue that saves the derivative)
+__device__ __forceinline__ float tv_act_with_grad_rt(int act, float z, float& g) {
+    if (act == TV_ACT_GELU) {
+        float e;
+        const float cdf = fmaf(0.5f, tv_erf_e(z * 0.70710678118654752f, e), 0.5f);
+        g = fmaf(z * 0.3989422804014327f, e, cdf);
+        return z * cdf;
+    }
+    if (act == TV_ACT_SILU) {
+        const float s = tv_sigmoid(z);
+        g = s * fmaf(z, 1.0f - s, 1.0f);
+        return z * s;
+    }
+    g = 1.0f;
+    return z;
 }
 
 // ---------------------------------------------------------------------------

@@ -44,6 +44,7 @@ struct IgemmArgs {
     int shuffle;
     int act;
     int aux_act;
+    int pre_deriv;     // pre receives act'(pre-activation) (TV_ACT_SAVE_DERIV)
     int hw_shift, w_shift;  // log2 of h_out*w_out / w_out when both are powers of two, else -1
     unsigned x_bytes, w_bytes;  // MODE 2: extents of the two buffers (< 2 GiB)
 };
@@ -236,7 +237,16 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
             const f32x4 v1 = *(const f32x4*)(ebuf + rl * ERS + c8 * 32 + 16);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             bf16x8 z;
-            if (p.pre) {
+            const bool save_deriv = p.pre && p.pre_deriv;
+            if (save_deriv) {   // save act'(pre-activation): the backward epilogue then is one multiply per element
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float g;
+                    v[e] = tv_act_with_grad_rt(p.act, v[e], g);
+                    z[e] = (bf16)g;
+                }
+                *(bf16x8*)(p.pre + off) = z;
+            } else if (p.pre) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) z[e] = (bf16)v[e];
                 *(bf16x8*)(p.pre + off) = z;
@@ -248,11 +258,18 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
                 }
+                if (p.aux_act == TV_ACT_DERIV) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= tv_act_grad_rt(p.aux_act, (float)av[e]);
+                    for (int e = 0; e < 8; ++e) v[e] *= (float)av[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= tv_act_grad_rt(p.aux_act, (float)av[e]);
+                }
             } else if (p.act != TV_ACT_NONE || p.res) {
+                if (!save_deriv) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = tv_act_rt(p.act, v[e]);
+                    for (int e = 0; e < 8; ++e) v[e] = tv_act_rt(p.act, v[e]);
+                }
                 if (p.res) {
                     const bf16x8 rv = *(const bf16x8*)(p.res + off);
 #pragma unroll
@@ -1411,7 +1428,7 @@ extern "C" int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, 
 
 extern "C" int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const void* w, const void* residual,
                                    const void* aux_pre_act, int aux_act, void* out, void* stream) {
-    TV_CHECK_ARG(aux_pre_act && aux_act >= 0 && aux_act <= 2 && d && d->act == TV_ACT_NONE,
+    TV_CHECK_ARG(aux_pre_act && aux_act >= 0 && aux_act <= TV_ACT_DERIV && d && d->act == TV_ACT_NONE,
                  "tv_igemm_nt_actgrad: needs the saved pre-activation, a valid activation id and desc.act == NONE");
     return igemm_nt_impl(d, x, w, nullptr, residual, nullptr, out, aux_pre_act, aux_act, stream);
 }
@@ -1426,7 +1443,9 @@ static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, co
     TV_CHECK_ARG(d->batch > 0 && d->h_in > 0 && d->w_in > 0 && d->h_out > 0 && d->w_out > 0, "tv_igemm_nt: empty geometry");
     TV_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "tv_igemm_nt: bad taps");
     TV_CHECK_ARG((d->up_shift | 1) == 1 && (d->dil_mask | 1) == 1, "tv_igemm_nt: up_shift/dil_mask must be 0 or 1");
-    TV_CHECK_ARG(d->act >= 0 && d->act <= 2, "tv_igemm_nt: unknown activation %d", d->act);
+    TV_CHECK_ARG(d->act >= 0 && (d->act & ~TV_ACT_SAVE_DERIV) <= 2, "tv_igemm_nt: unknown activation %d", d->act);
+    TV_CHECK_ARG(!(d->act & TV_ACT_SAVE_DERIV) || (pre_act && (d->act & ~TV_ACT_SAVE_DERIV) != TV_ACT_NONE),
+                 "tv_igemm_nt: TV_ACT_SAVE_DERIV needs an activation and a pre_act buffer");
     TV_CHECK_ARG(d->store_shuffle >= 0 && d->store_shuffle <= 2, "tv_igemm_nt: store_shuffle must be 0, 1 or 2");
     const long long M = (long long)d->batch * d->h_out * d->w_out;
     TV_CHECK_ARG(M < (1ll << 31) && (long long)d->batch * d->h_in * d->w_in < (1ll << 31), "tv_igemm_nt: too many pixels");
@@ -1456,7 +1475,8 @@ static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, co
     a.up_shift = d->up_shift; a.dil_mask = d->dil_mask;
     a.tiles_n = 1;
     a.shuffle = d->store_shuffle;
-    a.act = d->act;
+    a.act = d->act & ~TV_ACT_SAVE_DERIV;
+    a.pre_deriv = (d->act & TV_ACT_SAVE_DERIV) ? 1 : 0;
     {
         auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; };
         a.w_shift = lg(d->w_out);

@@ -18,6 +18,7 @@ CSRC = os.path.join(PKG_ROOT, "csrc")
 SO_PATH = os.environ.get("TV_HIP_SO") or os.path.join(_HERE, "libtransvae_hip.so")   # TV_HIP_SO: probe builds only
 
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+ACT_DERIV, ACT_SAVE_DERIV = 3, 16   # include/transvae_hip.h: saved tensor = act'(pre-activation)
 
 
 class ConvDesc(C.Structure):

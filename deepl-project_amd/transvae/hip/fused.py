@@ -6,7 +6,9 @@ activation, autograd's add kernels wherever a tensor has two consumers (every re
 fills.  Here each block's backward is written out explicitly, so that
 
   * activation backward rides in the epilogue of the data-gradient GEMM that produces the incoming
-    gradient (`tv_igemm_nt_actgrad`: out = (acc + residual) * act'(pre)),
+    gradient (`tv_igemm_nt_actgrad`: out = (acc + residual) * act'(pre)); the forward epilogue saves act'(pre)
+    itself (`conv_forward(..., want_pre="deriv")`, from the erf / exponential it computes anyway), so the tensors
+    called `pre_*` below hold the DERIVATIVE and the backward epilogue is one multiply per element,
   * the second gradient of a residual stream is added inside GroupNorm-backward / row-norm-backward
     (`dres`) or a GEMM epilogue (`residual`),
   * nothing is materialised twice.
@@ -15,6 +17,8 @@ Math and parameter layouts are those of ops.py; reference lines are cited there 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -22,6 +26,13 @@ from . import ops
 from .ops import BF16, _p, _stream, conv_dgrad, conv_forward, conv_wgrad
 
 GELU, SILU, NONE = L.ACT_GELU, L.ACT_SILU, L.ACT_NONE
+# what the forward saves for an activation: its derivative (default) or the pre-activation (TV_SAVE_DERIV=0, A/B timing)
+_SAVE_DERIV = os.environ.get("TV_SAVE_DERIV", "1") != "0"
+_WANT = "deriv" if _SAVE_DERIV else True
+
+
+def _aux_act(act_id: int) -> int:
+    return L.ACT_DERIV if _SAVE_DERIV else act_id
 
 
 # ------------------------------------------------------------------------------------------------
@@ -204,10 +215,10 @@ class ConvFFNBranchFn(torch.autograd.Function):
         T, d = t.shape
         train = any(ctx.needs_input_grad)
         r = rownorm_fwd(t, None, 0, eps_rms, 1e-5)
-        u, pre_u, geo_in, w_in_c = conv_forward(r, w_in, _c(b_in), None, "linear", GELU, train)
-        c1, pre_c1, geo1, w1c = conv_forward(u, w1, _c(b1), None, "linear", GELU, train)
+        u, pre_u, geo_in, w_in_c = conv_forward(r, w_in, _c(b_in), None, "linear", GELU, train and _WANT)
+        c1, pre_c1, geo1, w1c = conv_forward(u, w1, _c(b1), None, "linear", GELU, train and _WANT)
         mid = c1.shape[1]
-        c2, pre_c2, geo2, w2c = conv_forward(c1.view(B, H, W, mid), w2, _c(b2), None, "c3s1", GELU, train)
+        c2, pre_c2, geo2, w2c = conv_forward(c1.view(B, H, W, mid), w2, _c(b2), None, "c3s1", GELU, train and _WANT)
         u2, _, geo3, w3c = conv_forward(c2.view(T, mid), w3, _c(b3), u, "linear", NONE, False)
         out, _, geo_out, w_out_c = conv_forward(u2, w_out, _c(b_out), t, "linear", NONE, False)
         ctx.geo = (geo_in, geo1, geo2, geo3, geo_out)
@@ -225,13 +236,13 @@ class ConvFFNBranchFn(torch.autograd.Function):
         g = g.contiguous()
         du2 = conv_dgrad(geo_out, w_out, g, u2.shape)                                   # [T,4d]
         dw_out, db_out = _wg(ctx, 9, 10, geo_out, w_out, u2, g)
-        gz_c2 = conv_dgrad(geo3, w3, du2, (T, mid), aux=pre_c2.view(T, mid), aux_act=GELU)   # d/d pre_c2
+        gz_c2 = conv_dgrad(geo3, w3, du2, (T, mid), aux=pre_c2.view(T, mid), aux_act=_aux_act(GELU))   # d/d pre_c2
         dw3, db3 = _wg(ctx, 7, 8, geo3, w3, c2.view(T, mid), du2)
         gz_c2 = gz_c2.view(B, H, W, mid)
-        gz_c1 = conv_dgrad(geo2, w2, gz_c2, (B, H, W, mid), aux=pre_c1.view(B, H, W, mid), aux_act=GELU)
+        gz_c1 = conv_dgrad(geo2, w2, gz_c2, (B, H, W, mid), aux=pre_c1.view(B, H, W, mid), aux_act=_aux_act(GELU))
         dw2, db2 = _wg(ctx, 5, 6, geo2, w2, c1.view(B, H, W, mid), gz_c2)
         gz_c1 = gz_c1.view(T, mid)
-        gz_u = conv_dgrad(geo1, w1, gz_c1, u.shape, residual=du2, aux=pre_u, aux_act=GELU)   # (W1^T gz_c1 + du2) * gelu'(pre_u)
+        gz_u = conv_dgrad(geo1, w1, gz_c1, u.shape, residual=du2, aux=pre_u, aux_act=_aux_act(GELU))   # (W1^T gz_c1 + du2) * gelu'(pre_u)
         dw1, db1 = _wg(ctx, 3, 4, geo1, w1, u, gz_c1)
         del du2
         dr = conv_dgrad(geo_in, w_in, gz_u, r.shape)
@@ -251,7 +262,7 @@ class DownsampleFn(torch.autograd.Function):
         dc, gdc, wdcc = None, None, None
         if wdc is not None:
             dc, _, gdc, wdcc = conv_forward(x, wdc, _c(bdc), None, "unshuf", NONE, False)
-        h, pre_h, g0, w0c = conv_forward(x, w0, _c(b0), None, "c3s1", SILU, any(ctx.needs_input_grad))
+        h, pre_h, g0, w0c = conv_forward(x, w0, _c(b0), None, "c3s1", SILU, any(ctx.needs_input_grad) and _WANT)
         out, _, g2, w2c = conv_forward(h, w2, _c(b2), dc, "c3s2", NONE, False)
         ctx.geo = (g0, g2, gdc)
         ctx.save_for_backward(x, h, pre_h, w0c, w2c, wdcc)
@@ -262,7 +273,7 @@ class DownsampleFn(torch.autograd.Function):
         x, h, pre_h, w0, w2, wdc = ctx.saved_tensors
         g0, g2, gdc = ctx.geo
         g = g.contiguous()
-        gz_h = conv_dgrad(g2, w2, g, h.shape, aux=pre_h, aux_act=SILU)
+        gz_h = conv_dgrad(g2, w2, g, h.shape, aux=pre_h, aux_act=_aux_act(SILU))
         dw2, db2 = _wg(ctx, 3, 4, g2, w2, h, g)
         dx = conv_dgrad(g0, w0, gz_h, x.shape)
         dw0, db0 = _wg(ctx, 1, 2, g0, w0, x, gz_h)
@@ -281,7 +292,7 @@ class UpsampleFn(torch.autograd.Function):
         dc, gdc, wdcc = None, None, None
         if wdc is not None:
             dc, _, gdc, wdcc = conv_forward(x, wdc, _c(bdc), None, "shuf", NONE, False)
-        h, pre_h, g1, w1c = conv_forward(x, w1, _c(b1), None, "c3up", SILU, any(ctx.needs_input_grad))
+        h, pre_h, g1, w1c = conv_forward(x, w1, _c(b1), None, "c3up", SILU, any(ctx.needs_input_grad) and _WANT)
         out, _, g3, w3c = conv_forward(h, w3, _c(b3), dc, "c3s1", NONE, False)
         ctx.geo = (g1, g3, gdc)
         ctx.save_for_backward(x, h, pre_h, w1c, w3c, wdcc)
@@ -292,7 +303,7 @@ class UpsampleFn(torch.autograd.Function):
         x, h, pre_h, w1, w3, wdc = ctx.saved_tensors
         g1, g3, gdc = ctx.geo
         g = g.contiguous()
-        gz_h = conv_dgrad(g3, w3, g, h.shape, aux=pre_h, aux_act=SILU)
+        gz_h = conv_dgrad(g3, w3, g, h.shape, aux=pre_h, aux_act=_aux_act(SILU))
         dw3, db3 = _wg(ctx, 3, 4, g3, w3, h, g)
         dx = conv_dgrad(g1, w1, gz_h, x.shape)
         dw1, db1 = _wg(ctx, 1, 2, g1, w1, x, gz_h)

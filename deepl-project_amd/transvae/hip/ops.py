@@ -179,8 +179,10 @@ class _Geo:
 
 
 # ---- the three passes of one layer as plain functions (shared by ConvFn and the fused block Functions) ----
-def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre: bool):
-    """Returns (out, pre_activation | None, geometry, contiguous fp32 weight)."""
+def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre):
+    """Returns (out, pre_activation | None, geometry, contiguous fp32 weight).
+    want_pre = "deriv": the second tensor is act'(pre-activation) instead (pass it to conv_dgrad with
+    aux_act = L.ACT_DERIV); falsy: nothing is saved."""
     _need_gpu(x, w)
     assert x.dtype == BF16 and x.is_contiguous(), "activations must be contiguous bf16 NHWC"
     assert w.dtype == torch.float32
@@ -188,6 +190,8 @@ def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre: bool):
     g = _Geo(mode, x, w)
     out = torch.empty(g.out_shape, dtype=BF16, device=x.device)
     pre = torch.empty_like(out) if (want_pre and act_id != L.ACT_NONE) else None
+    if pre is not None and want_pre == "deriv":
+        act_id |= L.ACT_SAVE_DERIV
     if residual is not None:
         assert residual.shape == out.shape and residual.dtype == BF16 and residual.is_contiguous()
     if bias is not None:

@@ -34,6 +34,12 @@ extern "C" {
 #define TV_ACT_NONE 0
 #define TV_ACT_GELU 1 /* exact (erf) GELU, R/transvae/modules/conv.py:56,86 */
 #define TV_ACT_SILU 2 /* R/transvae/modules/upsample.py:35,96 */
+/* Training-only variants of the saved tensor (no reference counterpart: autograd saves the pre-activation there).
+ * desc.act | TV_ACT_SAVE_DERIV: `pre_act` receives act'(pre-activation) instead of the pre-activation, computed from the
+ * same erf / exponential as the activation itself; tv_igemm_nt_actgrad(..., aux_act = TV_ACT_DERIV) then multiplies by
+ * the saved tensor directly -- the backward epilogue carries no transcendental arithmetic. */
+#define TV_ACT_DERIV 3
+#define TV_ACT_SAVE_DERIV 16
 
 /* library ------------------------------------------------------------------ */
 int tv_init(void);                 /* allocates the device zero page; idempotent */

@@ -131,6 +131,44 @@ def test_conv_forward_backward(case, dma):
         _lib.load().tv_set_dma(1)
 
 
+DERIV_CASES = [
+    ("linear", (300, 256), (384,), "gelu", False),
+    ("linear", (130, 96), (192,), "silu", True),
+    ("c3s1", (2, 16, 16, 192), (192, 3, 3), "gelu", True),
+    ("c3up", (1, 8, 16, 64), (96, 3, 3), "silu", False),
+]
+
+
+@pytest.mark.parametrize("case", DERIV_CASES, ids=[f"{c[0]}-{c[3]}" for c in DERIV_CASES])
+def test_saved_activation_derivative(case):
+    """want_pre="deriv" (TV_ACT_SAVE_DERIV): the saved tensor is act'(pre-activation), the output is unchanged, and the
+    data gradient with aux_act = TV_ACT_DERIV equals the one computed from the saved pre-activation."""
+    from transvae.hip import ops, _lib as L
+    mode, xs, ws, act, use_res = case
+    act_id = {"gelu": L.ACT_GELU, "silu": L.ACT_SILU}[act]
+    x, w, b = _mk(mode, xs, ws, seed=77)
+    xd, wd, bd = x.to(dev(), BF), w.to(dev()), b.to(dev())
+    y_pre, pre, g, _ = ops.conv_forward(xd, wd, bd, None, mode, act_id, True)
+    res = r16(gen(*y_pre.shape, seed=5)).to(dev(), BF) if use_res else None
+    y_pre, pre, g, _ = ops.conv_forward(xd, wd, bd, res, mode, act_id, True)
+    y_der, der, _, _ = ops.conv_forward(xd, wd, bd, res, mode, act_id, "deriv")
+    assert torch.equal(y_pre, y_der)
+    z = pre.float().cpu().requires_grad_(True)
+    (F.gelu(z) if act == "gelu" else F.silu(z)).sum().backward()
+    # the kernel derives from the unrounded pre-activation, the reference from its bf16 rounding
+    assert rel(der, z.grad) < 8e-3
+    assert (der.float().cpu() - z.grad).abs().max() < 0.03
+    # consumer: data gradient of a following linear layer, multiplied by the saved tensor
+    C = y_pre.shape[-1]
+    T = y_pre.numel() // C
+    w2 = r16(gen(64, C, seed=9, scale=C ** -0.5)).to(dev())
+    gz = r16(gen(T, 64, seed=10)).to(dev(), BF)
+    g2 = ops._Geo("linear", y_pre.view(T, C), w2)
+    d_pre = ops.conv_dgrad(g2, w2, gz, (T, C), None, pre.view(T, C), act_id)
+    d_der = ops.conv_dgrad(g2, w2, gz, (T, C), None, der.view(T, C), L.ACT_DERIV)
+    assert rel(d_der, d_pre) < 8e-3
+
+
 # 3x3 stride-1 halo-tile kernel (csrc/igemm_nt.hip: conv3x3_halo_kernel): every tile shape, image borders inside and
 # between tiles, several channel chunks, non-power-of-two grids; (bm, bn) forces the tile through the tuning hook.
 HALO_CASES = [
