@@ -84,7 +84,7 @@ def time_dominant_kernel(mb: int, res: int, dev):
         with open(pmc) as f:
             j = json.load(f)
         traffic = round(j["hbm_bytes_per_launch"] * mb / j["images"])
-    return {"bound": "mfma", "kernel": "conv3x3_halo_kernel<256,192,4,2,3> via tv_igemm_nt (conv3x3 192->192 @%dx%d, %d images)" % (res, res, mb),
+    return {"bound": "mfma", "kernel": "conv3x3_halo_kernel<256,192,4,2,3,0> via tv_igemm_nt (conv3x3 192->192 @%dx%d, %d images)" % (res, res, mb),
             "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
             "traffic": traffic}

@@ -87,6 +87,21 @@ def pack_weight(w: torch.Tensor, want_fwd: bool, want_t: bool, flip: bool):
     return d, dt
 
 
+def _derived_weight(w: torch.Tensor, kind: str, build):
+    """Operands DERIVED from a parameter by a chain of small torch ops (polyphase / parity forms): same cache, same key
+    rule as pack_weight -- they cost 50-100 launch-bound kernels each, once per optimizer step instead of per micro-batch."""
+    if _pack_cache is None:
+        return build()
+    base = w._base if w._base is not None else w
+    if not isinstance(base, torch.nn.Parameter):
+        return build()
+    key = (id(base), base._version, w.data_ptr(), tuple(w.shape), kind)
+    hit = _pack_cache.get(key)
+    if hit is None:
+        hit = _pack_cache[key] = build()
+    return hit
+
+
 def _desc(**kw) -> L.ConvDesc:
     d = L.ConvDesc()
     for k in ("up_shift", "dil_mask", "act", "store_shuffle", "pad"):
@@ -197,7 +212,7 @@ def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre):
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == g.Cout
     if mode == "c3up":   # polyphase: one 2x2-footprint GEMM on the (H+1) x (W+1) cell grid, four phases as column quadrants
-        wb = _up_fwd_weight(w, g.Cout, g.Cin)
+        wb = _derived_weight(w, "up_fwd", lambda: _up_fwd_weight(w, g.Cout, g.Cin))
         d = _desc(batch=g.B, h_in=g.H, w_in=g.W, c_in=g.Cin, ldx=g.Cin, h_out=g.H + 1, w_out=g.W + 1, c_out=4 * g.Cout,
                   ldo=g.Cout, kh=2, kw=2, stride=1, pad=1, act=act_id, store_shuffle=2)
         igemm(d, x, wb, bias.repeat(4) if bias is not None else None, residual, pre, out)
@@ -320,12 +335,12 @@ def conv_dgrad(g: _Geo, w, gz, x_shape, residual=None, aux=None, aux_act: int = 
         # (py = 1), likewise in x.  One GEMM over the low-resolution grid with a 2x2 footprint and 4*Cin columns -- class
         # (py, px) in column quadrant 2*py+px, its unused taps zero -- stored pixel-shuffled: 16 tap-GEMMs instead of the
         # 36 of a zero-dilated 3x3 on the full-resolution grid (9 are the algorithmic minimum).
-        wd = _s2_parity_weight(w, g.Cout, g.Cin)
+        wd = _derived_weight(w, "s2_parity", lambda: _s2_parity_weight(w, g.Cout, g.Cin))
         d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.Ho, w_out=g.Wo, c_out=4 * g.Cin, ldo=g.Cin,
                   kh=2, kw=2, stride=1, pad=0, store_shuffle=1)
         _igemm_bwd(d, gz, wd, residual, aux, aux_act, dx)
     elif m == "c3up":   # adjoint of the polyphase form: 4x4 / stride-2 / pad-1 convolution of the high-resolution gradient
-        wd = _up_dgrad_weight(w, g.Cout, g.Cin)
+        wd = _derived_weight(w, "up_dgrad", lambda: _up_dgrad_weight(w, g.Cout, g.Cin))
         d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
                   kh=4, kw=4, stride=2, pad=1)
         _igemm_bwd(d, gz, wd, residual, aux, aux_act, dx)

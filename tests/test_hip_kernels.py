@@ -291,6 +291,30 @@ def test_packed_weight_cache():
     assert d1.data_ptr() != d2.data_ptr()
 
 
+@torch.no_grad()   # (as inside an autograd Function's forward)
+def test_derived_weight_cache():
+    """Polyphase / parity operands derived from a parameter are built once per version of the parameter inside a
+    packed_weight_cache() block, and the cached operand gives the same convolution as a fresh one."""
+    from transvae.hip import ops, _lib as L
+    conv = torch.nn.Conv2d(64, 32, 3, padding=1).to(dev()).to(memory_format=torch.channels_last)
+    x = r16(gen(2, 6, 8, 64, seed=1)).to(dev(), BF)
+
+    def w():
+        return conv.weight.permute(0, 2, 3, 1)
+    y_ref = ops.conv_forward(x, w(), None, None, "c3up", L.ACT_NONE, False)[0]
+    with ops.packed_weight_cache():
+        n0 = len(ops._pack_cache)
+        y1 = ops.conv_forward(x, w(), None, None, "c3up", L.ACT_NONE, False)[0]
+        n1 = len(ops._pack_cache)
+        y2 = ops.conv_forward(x, w(), None, None, "c3up", L.ACT_NONE, False)[0]
+        assert n1 == n0 + 1 and len(ops._pack_cache) == n1            # second call: a hit
+        assert torch.equal(y1, y_ref) and torch.equal(y2, y_ref)
+        conv.weight.mul_(0.5)
+        y3 = ops.conv_forward(x, w(), None, None, "c3up", L.ACT_NONE, False)[0]
+        assert len(ops._pack_cache) == n1 + 1                          # new version: rebuilt
+        assert rel(y3, 0.5 * y_ref.float()) < 1e-2
+
+
 def test_pack_weight():
     from transvae.hip import ops
     w = gen(40, 9, 72, seed=3)
