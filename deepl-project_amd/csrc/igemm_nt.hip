@@ -136,8 +136,10 @@ constexpr int epilogue_lds_bytes(int nwaves) {
 // EPI = 1: plain row store + residual add, no activation (ffn_out / proj / ResBlock conv2 and every data gradient that
 //          adds a second gradient of the same tensor).  ALL of a pass's residual loads are issued before the tile is
 //          parked, so their latency runs under the LDS round trip instead of once per pair of row chunks: +3...37 % on
-//          these layers (tools/probes/ab_epilogue.py).  The same treatment of the activation-gradient epilogue measured
-//          -13...+5 % (its erf / exp arithmetic is the cost there, and the unrolled form is large): it stays on EPI 0.
+//          these layers (tools/probes/ab_epilogue.py).
+// EPI = 2: activation gradient from a saved DERIVATIVE (aux_act == TV_ACT_DERIV), no residual: out = acc * aux, loads
+//          issued early as in EPI 1: +2...22 %.  (With a residual as well -- two batches of loads in flight -- the form
+//          measured -0...5 %, and with the erf / exp arithmetic of act'(pre-activation) inside -13...+5 %: EPI 0.)
 template <int WTM, int WTN, int EPI, class RowMap>
 __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[WTM / 16][WTN / 16], char* smem, int wave, int lane,
                                          int nw0, RowMap m_of_row) {
@@ -155,7 +157,7 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
     for (int ps = 0; ps < PASSES; ++ps) {
         constexpr int ITER = (RH * CPW + 63) / 64;
         [[maybe_unused]] unsigned eoff[EPI ? ITER : 1];   // in 16-byte units (host checks the range); ~0u: outside the tensor
-        [[maybe_unused]] bf16x8 erv[EPI ? ITER : 1];
+        [[maybe_unused]] bf16x8 erv[EPI ? ITER : 1];   // residual (EPI 1) or saved derivative (EPI 2)
         if constexpr (EPI != 0) {
 #pragma unroll
             for (int k = 0; k < ITER; ++k) {
@@ -166,9 +168,10 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
                 const bool ok = idx < RH * CPW && m < p.M && n < p.N;
                 eoff[k] = ok ? (unsigned)(((long long)m * p.ldo + n) >> 3) : ~0u;
             }
+            const bf16* __restrict__ esrc = EPI == 2 ? p.aux : p.res;
 #pragma unroll
             for (int k = 0; k < ITER; ++k)
-                if (eoff[k] != ~0u) erv[k] = *(const bf16x8*)(p.res + (size_t)eoff[k] * 8);
+                if (eoff[k] != ~0u) erv[k] = *(const bf16x8*)(esrc + (size_t)eoff[k] * 8);
         }
 #pragma unroll
         for (int ii = 0; ii < MFP; ++ii) {
@@ -195,7 +198,7 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
                 const f32x4 v1 = *(const f32x4*)(ebuf + rl * ERS + c8 * 32 + 16);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)erv[k][e];
+                for (int e = 0; e < 8; ++e) v[e] = EPI == 2 ? v[e] * (float)erv[k][e] : v[e] + (float)erv[k][e];
                 bf16x8 z;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) z[e] = (bf16)v[e];
@@ -1203,9 +1206,10 @@ constexpr int LDS_MAX = 160 * 1024;
 
 bool g_epi_modes = true;   // compile-time epilogue forms (tv_set_igemm_epilogue(0): the generic one everywhere, for A/B timing)
 
-// which epilogue form a call takes (see epilogue<>): 1 = residual add only, 0 = everything else
+// which epilogue form a call takes (see epilogue<>): 1 = residual add only, 2 = saved-derivative multiply, 0 = the rest
 int epilogue_mode(const IgemmArgs& a) {
-    if (!g_epi_modes || a.shuffle || a.pre || a.aux || ((long long)a.M * a.ldo >> 3) >= 0xffffffffll) return 0;
+    if (!g_epi_modes || a.shuffle || a.pre || ((long long)a.M * a.ldo >> 3) >= 0xffffffffll) return 0;
+    if (a.aux) return (a.aux_act == TV_ACT_DERIV && !a.res) ? 2 : 0;
     return (a.res && a.act == TV_ACT_NONE) ? 1 : 0;
 }
 
@@ -1235,6 +1239,7 @@ int launch_one(const IgemmArgs& a_in, hipStream_t s) {
         const int epi = epilogue_mode(a);
         if constexpr (MODE == 2 && BM * BN >= 128 * 128) {   // (the bring-up modes and the narrow tiles keep the one generic epilogue)
             if (epi == 1) { go(std::integral_constant<int, 1>{}); return 0; }
+            if (epi == 2) { go(std::integral_constant<int, 2>{}); return 0; }
         }
         go(std::integral_constant<int, 0>{});
         return 0;
@@ -1331,6 +1336,7 @@ int launch_halo_one(const IgemmArgs& a_in, hipStream_t s) {
         };
         const int epi = epilogue_mode(a);
         if (epi == 1) go(std::integral_constant<int, 1>{});
+        else if (epi == 2) go(std::integral_constant<int, 2>{});
         else go(std::integral_constant<int, 0>{});
         return 0;
     }
