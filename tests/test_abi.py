@@ -18,6 +18,20 @@ def test_header_and_binding_agree():
     assert header_symbols() == sorted(_lib.SIGNATURES)
 
 
+def test_activation_ids_agree():
+    """TV_ACT_* in the public header, the kernels' common.h and the ctypes binding are the same numbers."""
+    from transvae.hip import _lib
+
+    def defines(path):
+        return {k: int(v) for k, v in re.findall(r"#define\s+(TV_ACT_[A-Z_]+)\s+(\d+)", open(path).read())}
+    pub = defines(os.path.join(ROOT, "include", "transvae_hip.h"))
+    dev = defines(os.path.join(ROOT, "deepl-project_amd", "csrc", "common.h"))
+    assert pub == dev and len(pub) == 5, (pub, dev)
+    assert (pub["TV_ACT_NONE"], pub["TV_ACT_GELU"], pub["TV_ACT_SILU"]) == (_lib.ACT_NONE, _lib.ACT_GELU, _lib.ACT_SILU)
+    assert (pub["TV_ACT_DERIV"], pub["TV_ACT_SAVE_DERIV"]) == (_lib.ACT_DERIV, _lib.ACT_SAVE_DERIV)
+    assert pub["TV_ACT_SAVE_DERIV"] & (pub["TV_ACT_GELU"] | pub["TV_ACT_SILU"] | pub["TV_ACT_DERIV"]) == 0
+
+
 def test_library_loads_and_exports_every_symbol():
     from transvae.hip import _lib
     _lib.build()
