@@ -8,10 +8,18 @@
 One "step" = one optimizer step over the GLOBAL batch (256 images, 256x256, TransVAE-Large
 f16d32): forward + backward of every micro-batch, gradient all-reduce (N>1, last micro-batch
 only), clip-norm 1.0, AdamW(lr 1e-4, betas (0.9, 0.95), wd 0) -- R/train.py:557-646,681-687.
-Loss = L1 + 1e-8 KL (the closed-form terms of R/transvae/losses/vae_loss.py; LPIPS/VF need external
+Loss = L1 + 1e-8 KL (the closed-form terms of R/transvae/losses/vae_loss.py:83-84,94-96; LPIPS/VF need external
 networks and are out of scope).  The global batch is FIXED as N grows ("strong" scaling).
 Synthetic data (torch.rand images) and random fan-in-scaled weights of the exact architecture: the
-reference init overflows to NaN in forward, and no checkpoint exists.
+reference init overflows to NaN in forward, and no checkpoint exists.  The numerical policy is
+the reference's bf16 trainer's ("with the P/ clamps enabled"): the model clamps mu / logvar
+(P/.../transvae.py:186-196,243-245), the loss clamps logvar (R/train_2.py:316-318), the learning rate follows
+the linear warm-up of R/train_2.py:266-273 (--lr-warmup-steps, default 1000 like the reference), and a step
+with non-finite gradients is skipped on the device (R/train_2.py:328-338).  A run in which ANY step's loss is
+non-finite or any step was skipped prints no metric line and exits non-zero.
+
+--resolutions 256 512 alternates the resolution step by step (BASELINE config 4, /root/reference README.md:192-203:
+documented, never implemented there); every rank runs the same resolution in a given step.
 
 Rank 0 prints ONE JSON line.  `roofline` times the dominant kernel (the 192->192 3x3 implicit-GEMM
 convolution of the 256x256 stages, tv_igemm_nt) live with HIP events on the launch stream;
@@ -90,8 +98,9 @@ def time_dominant_kernel(mb: int, res: int, dev):
             "traffic": traffic}
 
 
-def cpu_baseline(variant: str, res: int, threads: int):
-    """The oracle (CPU restatement of the reference path) on ONE image: fwd + bwd + clip + AdamW."""
+def cpu_baseline(variant: str, res: int, threads: int, lr: float):
+    """The oracle (CPU restatement of the reference path) on ONE image: the SAME step as the GPU leg -- forward with the
+    P/ clamps, L1 + 1e-8 KL with the logvar clamp, backward, clip-norm 1.0, AdamW at the warm-up learning rate."""
     from oracle import transvae_oracle as O
     torch.set_num_threads(threads)
     cfg = O.variant_config(variant, 16, 32)
@@ -112,18 +121,22 @@ def cpu_baseline(variant: str, res: int, threads: int):
             t = 1.0 + 0.1 * torch.randn(s, generator=g)
         sd[k] = t.requires_grad_(True)
     params = [v for v in sd.values() if v.requires_grad]
-    opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0)
+    opt = torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.95), weight_decay=0.0)
     x = torch.rand(1, 3, res, res, generator=g)
     eps = torch.randn(1, 32, res // 16, res // 16, generator=g)
     t0 = time.time()
-    recon, mu, logvar = O.forward(x, sd, cfg, eps)
-    loss = O.bench_loss(recon, x, mu, logvar.clamp(-30, 20))
+    recon, mu, logvar = O.forward(x, sd, cfg, eps, clamp=True)
+    loss = O.bench_loss(recon, x, mu, logvar, clamp_logvar=True)
     loss.backward()
     torch.nn.utils.clip_grad_norm_(params, 1.0)
     opt.step()
     dt = time.time() - t0
     return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"1 image, TransVAE-{variant} f16d32 {res}x{res}, fp32 oracle fwd+bwd+clip+AdamW, {dt:.1f} s"}
+            "sample": f"1 image, TransVAE-{variant} f16d32 {res}x{res}, fp32 oracle fwd+bwd+clip+AdamW "
+                      f"(same clamps / loss / optimizer as the GPU leg), {dt:.1f} s",
+            # the reference's OWN fp32 CPU path cannot travel to the GPU box; timed in the build container
+            "reference_cpu_path": {"value": 0.019, "unit": "images/sec", "cores": 8, "where": "build container (8 cores)",
+                                   "sample": "TransVAE-large f16d32 256x256, batch 2, fwd+bwd+clip+AdamW, 104.7 s/step"}}
 
 
 def main():
@@ -133,6 +146,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--variant", default="large")
     ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--resolutions", type=int, nargs="+", default=None,
+                    help="alternate these resolutions step by step (BASELINE config 4: --resolutions 256 512 --global-batch 128)")
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--lr-warmup-steps", type=int, default=1000, help="linear warm-up of R/train_2.py:266-273 (0 = constant lr)")
+    ap.add_argument("--no-clamp", action="store_true", help="model without the P/ clamps (for the guard's A/B only)")
     ap.add_argument("--global-batch", type=int, default=256)
     ap.add_argument("--micro-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,24 +185,26 @@ def main():
 
     from transvae import TransVAE
     from transvae.hip import _lib
-    from transvae.parallel import shard_range, train_step, vae_bench_loss, wrap_ddp
+    from transvae.parallel import shard_range, train_step, vae_bench_loss, warmup_lr, wrap_ddp
     _lib.load()  # fails loudly if the HIP library is missing
 
     torch.manual_seed(0)
     with torch.device(dev):
-        model = TransVAE(variant=args.variant, compression_ratio=16, latent_dim=32)
+        model = TransVAE(variant=args.variant, compression_ratio=16, latent_dim=32, clamp_latent=not args.no_clamp)
     init_scaled_(model, seed=0)
     model.train()
     ddp = wrap_ddp(model, dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
 
     start, count = shard_range(args.global_batch, world, rank)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1000 + rank)
-    x = torch.rand(count, 3, args.res, args.res, device=dev, generator=gen)
-    lat = args.res // 16
+    resolutions = args.resolutions or [args.res]
+    xs = {r: torch.rand(count, 3, r, r, device=dev, generator=gen) for r in resolutions}
+    micro = {r: max(1, args.micro_batch * 256 * 256 // (r * r)) for r in resolutions}   # same pixels per micro-batch
 
     def forward_loss(m, xb):
+        lat = xb.shape[-1] // 16
         eps = torch.randn(xb.shape[0], 32, lat, lat, device=dev, generator=gen)
         recon, mu, logvar = m(xb, eps=eps)
         return vae_bench_loss(recon, xb, mu, logvar)
@@ -195,18 +215,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    counters = {}
+    opt_step = [0]
+
+    def one_step():
+        r = resolutions[opt_step[0] % len(resolutions)]
+        lr = warmup_lr(args.lr, opt_step[0], args.lr_warmup_steps)     # a python float: no device sync
+        for gr in opt.param_groups:
+            gr["lr"] = lr
+        opt_step[0] += 1
+        return train_step(ddp, opt, xs[r], micro[r], forward_loss, 1.0, args.global_batch, counters)
+
     if rank == 0:
-        log(f"{args.variant} f16d32 {args.res}px global batch {args.global_batch} on {world} GPU(s), "
-            f"{count} img/rank in micro-batches of {args.micro_batch}")
+        log(f"{args.variant} f16d32 {'/'.join(map(str, resolutions))}px global batch {args.global_batch} on {world} GPU(s), "
+            f"{count} img/rank in micro-batches of {', '.join(str(micro[r]) for r in resolutions)}")
+    losses = []
     for i in range(args.warmup):
-        loss = train_step(ddp, opt, x, args.micro_batch, forward_loss, 1.0, args.global_batch)
+        loss = one_step()
+        losses.append(loss)
         if rank == 0:
             torch.cuda.synchronize()
-            log(f"warmup {i}: loss {float(loss):.4f}  mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+            log(f"warmup {i}: loss {float(loss):.4f}  grad-norm {float(counters['grad_norm']):.3e}  "
+                f"mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = train_step(ddp, opt, x, args.micro_batch, forward_loss, 1.0, args.global_batch)
+        losses.append(one_step())       # device scalars; read after the timed region
         if rank == 0 and args.steps > 1:
             log(f"step {i} queued")
     sync()
@@ -214,33 +248,58 @@ def main():
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt)
-    final_loss = float(loss)
+    # every step's loss (all ranks' shares summed) and the number of skipped steps
+    lt = torch.stack([l.float() for l in losses])
+    if world > 1:
+        dist.all_reduce(lt)
+    lt = lt.cpu()
+    skipped = float(counters.get("skipped", torch.zeros(()))) if counters else 0.0
+    final_loss = float(lt[-1])
+    bad = (not bool(torch.isfinite(lt).all())) or skipped > 0
+    if bad:
+        if rank == 0:
+            log(f"FAILED: non-finite loss or skipped steps (skipped {skipped:.0f}); per-step losses: "
+                + " ".join(f"{float(v):.4g}" for v in lt))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(3)
 
     if rank == 0:
         ips = args.global_batch * args.steps / dt
-        gf = TRAIN_GFLOP_PER_IMAGE.get(args.variant) if args.res == 256 else (31419.3 if (args.variant, args.res) == ("large", 512) else None)
+        def gflop(r):
+            return TRAIN_GFLOP_PER_IMAGE.get(args.variant) if r == 256 else (31419.3 if (args.variant, r) == ("large", 512) else None)
+        per_res = [gflop(resolutions[(args.warmup + i) % len(resolutions)]) for i in range(args.steps)]
+        gf = None if any(v is None for v in per_res) else sum(per_res) / len(per_res)
+        res_name = "+".join(f"{r}x{r}" for r in resolutions)
         out = {
             "metric": "images/sec train step, TransVAE-Large f16d32 256px bs256",
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"TransVAE-{args.variant} f16d32 {args.res}x{args.res} train step "
+            "config": {"workload": f"TransVAE-{args.variant} f16d32 {res_name} train step "
                                    f"(fwd+bwd+grad all-reduce+clip+AdamW), global batch {args.global_batch}",
-                       "global_batch": args.global_batch, "micro_batch": args.micro_batch, "parallelism": f"dp{world}",
-                       "weights": "random fan-in scaled", "loss": "L1 + 1e-8 KL"},
+                       "global_batch": args.global_batch, "micro_batch": [micro[r] for r in resolutions] if len(resolutions) > 1 else args.micro_batch,
+                       "parallelism": f"dp{world}",
+                       "weights": "random fan-in scaled", "loss": "L1 + 1e-8 KL (vae_loss.py:83-84,94-96)",
+                       "numerics": "P/ clamps on mu/logvar, skip-on-non-finite guard",
+                       "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps},
             "final_loss": round(final_loss, 5),
+            "losses": [round(float(v), 5) for v in lt],
+            "skipped_steps": int(skipped),
             "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
         }
         if gf:
             out["model_tflops_per_gpu"] = round(ips * gf / 1e3 / world, 1)
             out["mfma_roofline_frac"] = round(ips * gf / 1e3 / world / PEAK_BF16_TFLOPS, 4)
         log("timing the dominant kernel")
-        out["roofline"] = time_dominant_kernel(min(args.micro_batch, count), args.res, dev)
+        out["roofline"] = time_dominant_kernel(min(args.micro_batch, count), 256, dev)
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle, 1 image) ...")
             del model, ddp, opt
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args.variant, args.res, max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+            out["cpu_baseline"] = cpu_baseline(args.variant, resolutions[0], max(1, min(args.cpu_threads, os.cpu_count() or 1)),
+                                               warmup_lr(args.lr, 0, args.lr_warmup_steps))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

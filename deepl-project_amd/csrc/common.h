@@ -21,6 +21,19 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 void tv_set_error(const char* fmt, ...);
 const void* tv_zero_page();  // >= 4 KiB of device zeros (source for padded LDS-DMA lanes)
 
+// Per-device "done once" flag for hipFuncSetAttribute (function attributes are per device: a second GPU in the same
+// process needs its own > 64 KiB dynamic-LDS opt-in).  Usage:  static TvPerDeviceOnce once;  if (once.first()) { ... }
+struct TvPerDeviceOnce {
+    bool done[64] = {};
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 #define TV_CHECK_ARG(cond, ...)        \
     do {                               \
         if (!(cond)) {                 \

@@ -1228,11 +1228,10 @@ int launch_one(const IgemmArgs& a_in, hipStream_t s) {
         dim3 grid((unsigned)(a.xcd_order ? 8 * a.tiles_n * ((tiles_m + 7) / 8) : tiles_m * a.tiles_n)), block(WGM * WGN * 64);
         auto go = [&](auto epi) {
             constexpr int EPI_MODE = decltype(epi)::value;
-            static bool attr_done = false;
-            if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in
+            static TvPerDeviceOnce attr_once;
+            if (attr_once.first()) {  // > 64 KiB of dynamic LDS needs the opt-in
                 (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE, EPI_MODE>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-                attr_done = true;
             }
             hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE, EPI_MODE>), grid, block, BYTES, s, a);
         };
@@ -1327,10 +1326,9 @@ int launch_halo_one(const IgemmArgs& a_in, hipStream_t s) {
         dim3 grid((unsigned)(a.xcd_order ? 8 * a.tiles_n * ((tiles_m + 7) / 8) : tiles_m * a.tiles_n)), block(NW * 64);
         auto go = [&](auto epi) {
             constexpr int EPI_MODE = decltype(epi)::value;
-            static bool attr_done = false;
-            if (!attr_done) {
+            static TvPerDeviceOnce attr_once;
+            if (attr_once.first()) {
                 (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BM, BN, WGM, WGN, BST, EPI_MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-                attr_done = true;
             }
             hipLaunchKernelGGL((conv3x3_halo_kernel<BM, BN, WGM, WGN, BST, EPI_MODE>), grid, block, BYTES, s, a);
         };

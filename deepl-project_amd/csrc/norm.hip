@@ -15,7 +15,12 @@ namespace {
 constexpr int GN_THREADS = 256;
 constexpr int GN_PIX_PER_BLOCK = 512;
 
-// ---- GroupNorm: per-(b,c) sum / sum of squares ------------------------------------------------
+// ---- GroupNorm: per-(b,c) sum / sum of squares ABOUT A PIVOT --------------------------------------
+// The one-pass form var = E[x^2] - mean^2 cancels when |mean| >> std (a residual stream whose mean has drifted; up to
+// ~400 K elements per group in fp32).  All sums are therefore taken about the pivot piv[b][c] = x[b, pixel 0, c] (the
+// same for every block of the image, so the partials still add in a fixed order), and gn_prepare merges the channels
+// of a group with Chan's parallel (mean, M2) update -- the result matches a two-pass / Welford computation like
+// ATen's group_norm to fp32 rounding.
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ part,
                                                               int hw, int C) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -31,11 +36,12 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16* __rest
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
         const bf16* base = x + ((size_t)b * hw) * C + chunk * 8;
+        const bf16x8 pv = *(const bf16x8*)base;   // pivot: pixel 0 of this image
         for (int p = p0 + prow; p < p1; p += rows) {
             const bf16x8 v = *(const bf16x8*)(base + (size_t)p * C);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float f = (float)v[e];
+                const float f = (float)v[e] - (float)pv[e];
                 s[e] += f;
                 q[e] = fmaf(f, f, q[e]);
             }
@@ -68,18 +74,27 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 }
 
 // per-channel scale/shift of image b from the channel sums:  h = x*scale[c] + shift[c]
-__device__ __forceinline__ void gn_prepare(const float* stats_b, const float* gamma, const float* beta, float* s_scale,
-                                           float* s_shift, float* s_mean, float* s_rstd, int hw, int C, int G, float eps) {
+__device__ __forceinline__ void gn_prepare(const float* stats_b, const bf16* x_b, const float* gamma, const float* beta,
+                                           float* s_scale, float* s_shift, float* s_mean, float* s_rstd, int hw, int C, int G,
+                                           float eps) {
     const int cpg = C / G;
+    const float inv_hw = 1.0f / (float)hw;
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        float su = 0.f, sq = 0.f;
+        // channel c: mean_c = piv_c + S_c / hw,  M2_c = Q_c - S_c^2 / hw  (sums about the pivot: no large cancellation);
+        // group: mean = avg_c mean_c,  M2 = sum_c M2_c + hw * sum_c (mean_c - mean)^2   (Chan et al., equal counts)
+        float msum = 0.f, m2 = 0.f;
         for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            su += stats_b[c * 2];
-            sq += stats_b[c * 2 + 1];
+            const float S = stats_b[c * 2], Q = stats_b[c * 2 + 1];
+            msum += (float)x_b[c] + S * inv_hw;
+            m2 += fmaxf(Q - S * S * inv_hw, 0.f);
         }
-        const float inv_n = 1.0f / ((float)cpg * (float)hw);
-        const float mean = su * inv_n;
-        const float var = fmaxf(sq * inv_n - mean * mean, 0.f);
+        const float mean = msum / (float)cpg;
+        float spread = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const float d = (float)x_b[c] + stats_b[c * 2] * inv_hw - mean;
+            spread = fmaf(d, d, spread);
+        }
+        const float var = (m2 + (float)hw * spread) / ((float)cpg * (float)hw);
         s_mean[g] = mean;
         s_rstd[g] = rsqrtf(var + eps);
     }
@@ -103,7 +118,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const bf16* __r
     float* s_mean = s_shift + C;
     float* s_rstd = s_mean + G;
     const int b = blockIdx.y;
-    gn_prepare(stats + (size_t)b * C * 2, gamma, beta, s_scale, s_shift, s_mean, s_rstd, hw, C, G, eps);
+    gn_prepare(stats + (size_t)b * C * 2, x + (size_t)b * hw * C, gamma, beta, s_scale, s_shift, s_mean, s_rstd, hw, C, G, eps);
     if (blockIdx.x == 0)
         for (int g = threadIdx.x; g < G; g += GN_THREADS) {
             mr[((size_t)b * G + g) * 2] = s_mean[g];

@@ -447,10 +447,9 @@ int launch_st(const WgradArgs& a, dim3 grid, hipStream_t s) {
     if constexpr (BYTES > 160 * 1024 || (TX / NWN) % 16 != 0 || (STAGES == 3 && (!uniform || NWN != 4 || !wgrad_pipe<TG, TX, NWN>()))) {
         return -1;
     } else {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static TvPerDeviceOnce attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute((const void*)wgrad_tn_kernel<TG, TX, BKP, NWN, FAST, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-            attr_done = true;
         }
         hipLaunchKernelGGL((wgrad_tn_kernel<TG, TX, BKP, NWN, FAST, STAGES>), grid, dim3(128 * NWN), BYTES, s, a);
         return 0;
@@ -610,6 +609,7 @@ static int wgrad_impl(const tv_conv_desc* d, const void* x, const void* gy, floa
     if (use256) {
         const int r = launch<256, 256>(a, s, plan_only);
         if (plan_only) return r;
+        if (r != 0) { tv_set_error("tv_wgrad_tn: no kernel for this configuration"); return TV_ERR_ARG; }
         TV_CHECK_LAUNCH("tv_wgrad_tn");
         return TV_OK;
     }
@@ -625,6 +625,7 @@ static int wgrad_impl(const tv_conv_desc* d, const void* x, const void* gy, floa
     else if (x64) r = launch<128, 64>(a, s, plan_only);
     else r = launch<128, 128>(a, s, plan_only);
     if (plan_only) return r;
+    if (r != 0) { tv_set_error("tv_wgrad_tn: no kernel for this configuration"); return TV_ERR_ARG; }
     TV_CHECK_LAUNCH("tv_wgrad_tn");
     return TV_OK;
 }

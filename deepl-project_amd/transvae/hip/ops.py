@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import functools
 from typing import Optional
 
 import torch
@@ -33,6 +34,31 @@ def _p(t: Optional[torch.Tensor]):
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require(cond: bool, msg: str):
+    """Operand checks that guard memory safety are real errors (they must survive `python -O`)."""
+    if not cond:
+        raise RuntimeError("transvae.hip: " + msg)
+
+
+def hip_entry(fn):
+    """Decorator for the public, reference-style entry points (Module.forward / encode / decode ...).
+
+    * The kernels launch on the CURRENT device's current stream and the library keeps per-device state (zero page,
+      LDS opt-ins): the call therefore runs under `torch.cuda.device(x.device)`, so a model moved with `.to('cuda:1')`
+      works without the caller having called `torch.cuda.set_device(1)`.
+    * The path has its own precision policy (bf16 storage, fp32 accumulation, fp32 parameter algebra).  Under the
+      reference trainers' `torch.autocast` (R/train.py:589-593, R/train_2.py:303-312) the small parameter folds
+      (W @ b, W * g) would silently turn bf16; autocast is switched off inside the call.
+    """
+    @functools.wraps(fn)
+    def wrapper(self, x, *args, **kwargs):
+        if isinstance(x, torch.Tensor) and x.is_cuda:
+            with torch.cuda.device(x.device), torch.autocast("cuda", enabled=False):
+                return fn(self, x, *args, **kwargs)
+        return fn(self, x, *args, **kwargs)   # CPU tensors: the first op raises (no CPU path)
+    return wrapper
 
 
 def _need_gpu(*ts):
@@ -69,7 +95,7 @@ def packed_weight_cache():
 def pack_weight(w: torch.Tensor, want_fwd: bool, want_t: bool, flip: bool):
     """w: fp32 [O, T, I] contiguous -> (bf16 [O,T,I] | None, bf16 [I,T,O] | None)."""
     O, T, I = w.shape
-    assert w.dtype == torch.float32 and w.is_contiguous()
+    _require(w.dtype == torch.float32 and w.is_contiguous(), "pack_weight needs a contiguous fp32 [O, T, I] tensor")
     key = None
     if _pack_cache is not None:
         base = w._base if w._base is not None else w
@@ -143,24 +169,24 @@ class _Geo:
     def __init__(self, mode: str, x: torch.Tensor, w: torch.Tensor):
         self.mode = mode
         if mode == "linear":
-            assert x.dim() == 2 and w.dim() == 2
+            _require(x.dim() == 2 and w.dim() == 2, "operand check failed: x.dim() == 2 and w.dim() == 2")
             self.B, self.H, self.W, self.Cin = x.shape[0], 1, 1, x.shape[1]
             self.Cout, self.KH, self.KW = w.shape[0], 1, 1
             self.Ho, self.Wo = 1, 1
             self.out_shape = (self.B, self.Cout)
         else:
-            assert x.dim() == 4 and w.dim() == 4, (mode, x.shape, w.shape)
+            _require(x.dim() == 4 and w.dim() == 4, "operand check failed: " + repr((mode, x.shape, w.shape)))
             self.B, self.H, self.W, self.Cin = x.shape
             self.Cout, self.KH, self.KW = w.shape[0], w.shape[1], w.shape[2]
             if mode == "c3s1":
                 self.Ho, self.Wo = self.H, self.W
             elif mode in ("c3s2", "unshuf"):
-                assert self.H % 2 == 0 and self.W % 2 == 0
+                _require(self.H % 2 == 0 and self.W % 2 == 0, "operand check failed: self.H % 2 == 0 and self.W % 2 == 0")
                 self.Ho, self.Wo = self.H // 2, self.W // 2
             elif mode == "c3up":
                 self.Ho, self.Wo = 2 * self.H, 2 * self.W
             elif mode == "shuf":
-                assert self.KH == 1 and self.KW == 1 and self.Cout % 4 == 0
+                _require(self.KH == 1 and self.KW == 1 and self.Cout % 4 == 0, "operand check failed: self.KH == 1 and self.KW == 1 and self.Cout % 4 == 0")
                 self.Ho, self.Wo = self.H, self.W          # GEMM grid; stored to [B,2H,2W,Cout/4]
             else:
                 raise ValueError(f"unknown conv mode {mode}")
@@ -168,9 +194,9 @@ class _Geo:
                 self.out_shape = (self.B, 2 * self.H, 2 * self.W, self.Cout // 4)
             else:
                 self.out_shape = (self.B, self.Ho, self.Wo, self.Cout)
-        assert w.shape[-1] == self.Cin, (mode, tuple(x.shape), tuple(w.shape))
+        _require(w.shape[-1] == self.Cin, "operand check failed: " + repr((mode, tuple(x.shape), tuple(w.shape))))
         exp_k = {"linear": (1, 1), "c3s1": (3, 3), "c3s2": (3, 3), "c3up": (3, 3), "unshuf": (2, 2), "shuf": (1, 1)}[mode]
-        assert (self.KH, self.KW) == exp_k, (mode, tuple(w.shape))
+        _require((self.KH, self.KW) == exp_k, "operand check failed: " + repr((mode, tuple(w.shape))))
 
     def fwd_desc(self, act: int) -> L.ConvDesc:
         m = self.mode
@@ -199,8 +225,10 @@ def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre):
     want_pre = "deriv": the second tensor is act'(pre-activation) instead (pass it to conv_dgrad with
     aux_act = L.ACT_DERIV); falsy: nothing is saved."""
     _need_gpu(x, w)
-    assert x.dtype == BF16 and x.is_contiguous(), "activations must be contiguous bf16 NHWC"
-    assert w.dtype == torch.float32
+    _require(x.dtype == BF16 and x.is_contiguous(), "activations must be contiguous bf16 NHWC")
+    _require(w.dtype == torch.float32, f"weights must be fp32 master copies, got {w.dtype} (parameter algebra under autocast?)")
+    _require(x.device == w.device and x.device.index == torch.cuda.current_device(),
+             f"tensors on {x.device} / {w.device} but the current device is cuda:{torch.cuda.current_device()}")
     w = w.contiguous()
     g = _Geo(mode, x, w)
     out = torch.empty(g.out_shape, dtype=BF16, device=x.device)
@@ -208,9 +236,11 @@ def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre):
     if pre is not None and want_pre == "deriv":
         act_id |= L.ACT_SAVE_DERIV
     if residual is not None:
-        assert residual.shape == out.shape and residual.dtype == BF16 and residual.is_contiguous()
+        _require(residual.shape == out.shape and residual.dtype == BF16 and residual.is_contiguous(),
+                 "residual must be contiguous bf16 of the output's shape")
     if bias is not None:
-        assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == g.Cout
+        _require(bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == g.Cout,
+                 f"bias must be contiguous fp32 [{g.Cout}], got {bias.dtype} {tuple(bias.shape)}")
     if mode == "c3up":   # polyphase: one 2x2-footprint GEMM on the (H+1) x (W+1) cell grid, four phases as column quadrants
         wb = _derived_weight(w, "up_fwd", lambda: _up_fwd_weight(w, g.Cout, g.Cin))
         d = _desc(batch=g.B, h_in=g.H, w_in=g.W, c_in=g.Cin, ldx=g.Cin, h_out=g.H + 1, w_out=g.W + 1, c_out=4 * g.Cout,
@@ -475,7 +505,7 @@ class ConvFn(torch.autograd.Function):
         x, w, pre = ctx.saved_tensors
         g: _Geo = ctx.geo
         gy = gy.contiguous()
-        assert gy.dtype == BF16
+        _require(gy.dtype == BF16, "operand check failed: gy.dtype == BF16")
         gres = gy if ctx.has_res else None
         gz = act_backward(pre, gy, ctx.act_id) if ctx.act_id != L.ACT_NONE else gy
         need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
@@ -503,7 +533,7 @@ class GroupNormSiluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, groups: int, eps: float):
         _need_gpu(x, gamma, beta)
-        assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 4
+        _require(x.dtype == BF16 and x.is_contiguous() and x.dim() == 4, "operand check failed: x.dtype == BF16 and x.is_contiguous() and x.dim() == 4")
         B, H, W, Cc = x.shape
         lib = L.load()
         gamma = gamma.contiguous()
@@ -551,7 +581,7 @@ class RowNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, mode: int, eps_rms: float, eps_ln: float):
         _need_gpu(x, w)
-        assert x.dtype == BF16 and x.is_contiguous() and x.dim() == 2
+        _require(x.dtype == BF16 and x.is_contiguous() and x.dim() == 2, "operand check failed: x.dtype == BF16 and x.is_contiguous() and x.dim() == 2")
         T, Cc = x.shape
         lib = L.load()
         if w is not None:
@@ -596,12 +626,12 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, rope_tab, heads: int, scale: float):
         _need_gpu(qkv)
-        assert qkv.dtype == BF16 and qkv.is_contiguous() and qkv.dim() == 3
+        _require(qkv.dtype == BF16 and qkv.is_contiguous() and qkv.dim() == 3, "operand check failed: qkv.dtype == BF16 and qkv.is_contiguous() and qkv.dim() == 3")
         B, N, C3 = qkv.shape
-        assert C3 == 3 * heads * 64
+        _require(C3 == 3 * heads * 64, "operand check failed: C3 == 3 * heads * 64")
         lib = L.load()
         if rope_tab is not None:
-            assert rope_tab.dtype == torch.float32 and rope_tab.shape == (N, 4, 32) and rope_tab.is_contiguous()
+            _require(rope_tab.dtype == torch.float32 and rope_tab.shape == (N, 4, 32) and rope_tab.is_contiguous(), "operand check failed: rope_tab.dtype == torch.float32 and rope_tab.shape == (N, 4, 32) and rope_tab.is_contiguous()")
             L.check(lib.tv_rope_qk(_p(qkv), _p(rope_tab), B, N, heads, 0, _stream()), "tv_rope_qk")
         o = torch.empty((B, N, heads * 64), dtype=BF16, device=qkv.device)
         lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
@@ -659,7 +689,7 @@ class ToNchwFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, c0: int, Cc: int):
         _need_gpu(x)
-        assert x.dtype == BF16 and x.is_contiguous()
+        _require(x.dtype == BF16 and x.is_contiguous(), "operand check failed: x.dtype == BF16 and x.is_contiguous()")
         B, H, W, cpad = x.shape
         y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
         src = C.c_void_p(x.data_ptr() + 2 * c0)

@@ -17,6 +17,7 @@ import torch.utils.checkpoint
 from ..hip import ops
 from ..modules.blocks import ResBlock, TransVAEBlock
 from ..modules.upsample import Upsample
+from .encoder import _tap
 
 
 def _round32(n: int) -> int:
@@ -52,21 +53,23 @@ class TransVAEDecoder(nn.Module):
     def enable_gradient_checkpointing(self):
         self.gradient_checkpointing = True
 
-    def forward_nhwc(self, z: torch.Tensor) -> torch.Tensor:
-        """z: [B, latent, h, w] NCHW (fp32) -> padded reconstruction [B, H, W, 32k] bf16."""
+    @ops.hip_entry
+    def forward_nhwc(self, z: torch.Tensor, taps=None) -> torch.Tensor:
+        """z: [B, latent, h, w] NCHW (fp32) -> padded reconstruction [B, H, W, 32k] bf16.  taps: see the encoder."""
         L = self.latent_dim
         lp = _round32(L)
         zin = ops.to_nhwc(z, lp)
         w_in = F.pad(self.conv_in.weight.permute(0, 2, 3, 1), (0, lp - L))
-        h = ops.conv(zin, w_in, self.conv_in.bias, None, "c3s1")
+        h = _tap(taps, "decoder.conv_in", ops.conv(zin, w_in, self.conv_in.bias, None, "c3s1"))
         for i, stage in enumerate(self.stages):
-            for block in stage:
+            for j, block in enumerate(stage):
                 if self.gradient_checkpointing and self.training:
                     h = torch.utils.checkpoint.checkpoint(block.forward_nhwc, h, use_reentrant=False)
                 else:
                     h = block.forward_nhwc(h)
+                h = _tap(taps, f"decoder.stages.{i}.{j}", h)
             if i < len(self.upsamples):
-                h = self.upsamples[i].forward_nhwc(h)
+                h = _tap(taps, f"decoder.upsamples.{i}", self.upsamples[i].forward_nhwc(h))
         h = ops.group_norm_silu(h, self.norm_out.weight, self.norm_out.bias, 32, self.norm_out.eps)
         co = self.output_channels
         cp = _round32(co)
@@ -74,6 +77,7 @@ class TransVAEDecoder(nn.Module):
         b_out = F.pad(self.conv_out.bias, (0, cp - co))
         return ops.conv(h, w_out, b_out, None, "c3s1")
 
+    @ops.hip_entry
     def forward(self, z: torch.Tensor) -> torch.Tensor:
         y = self.forward_nhwc(z)
         return ops.to_nchw(y, 0, self.output_channels)

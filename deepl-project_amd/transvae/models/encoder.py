@@ -18,6 +18,15 @@ from ..modules.blocks import ResBlock, TransVAEBlock
 from ..modules.upsample import Downsample
 
 
+def _tap(taps, key, h):
+    if taps is not None:
+        taps[key] = h.detach()
+        sub = taps.get("@" + key)
+        if sub is not None:
+            h = sub(h)
+    return h
+
+
 class TransVAEEncoder(nn.Module):
     NUM_CNN_STAGES = 2  # hard-coded in the reference (encoder.py:60)
 
@@ -54,22 +63,27 @@ class TransVAEEncoder(nn.Module):
         w = F.pad(self.conv_in.weight.permute(0, 2, 3, 1).reshape(-1, k), (0, kpad - k))
         return ops.linear(cols, w, self.conv_in.bias).view(B, H, W, -1)
 
-    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
-        """x: [B, C, H, W] image (any float dtype) -> [B, H/f, W/f, C_last] bf16."""
+    @ops.hip_entry
+    def forward_nhwc(self, x: torch.Tensor, taps=None) -> torch.Tensor:
+        """x: [B, C, H, W] image (any float dtype) -> [B, H/f, W/f, C_last] bf16.
+        taps: optional dict receiving every intermediate ([B,H,W,C] bf16) under the oracle's key names; an entry
+        '@' + key (callable) replaces that intermediate (precision attribution, tests/precision_report.py)."""
         f = 2 ** (self.num_stages - 1)
         if x.shape[-1] % f or x.shape[-2] % f:
             raise RuntimeError(f"input {tuple(x.shape[-2:])} must be divisible by {f}")
-        h = self._stem(x)
+        h = _tap(taps, "encoder.conv_in", self._stem(x))
         for i, stage in enumerate(self.stages):
-            for block in stage:
+            for j, block in enumerate(stage):
                 if self.gradient_checkpointing and self.training:
                     h = torch.utils.checkpoint.checkpoint(block.forward_nhwc, h, use_reentrant=False)
                 else:
                     h = block.forward_nhwc(h)
+                h = _tap(taps, f"encoder.stages.{i}.{j}", h)
             if i < len(self.downsamples):
-                h = self.downsamples[i].forward_nhwc(h)
+                h = _tap(taps, f"encoder.downsamples.{i}", self.downsamples[i].forward_nhwc(h))
         return h
 
+    @ops.hip_entry
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         h = self.forward_nhwc(x)
         return ops.to_nchw(h, 0, h.shape[-1])

@@ -90,6 +90,7 @@ class TransVAE(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     # ------------------------------------------------------------------ path
+    @ops.hip_entry
     def encode(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """x [B,C,H,W] -> (mu, logvar), each [B, latent, H/f, W/f] fp32.  conv_mu and conv_logvar run
         as ONE conv with 2*latent output channels (transvae.py:182-183)."""
@@ -113,9 +114,11 @@ class TransVAE(nn.Module):
             eps = torch.randn_like(std)
         return (mu_f + eps * std).to(mu.dtype)
 
+    @ops.hip_entry
     def decode(self, z: torch.Tensor) -> torch.Tensor:
         return self.decoder(z)
 
+    @ops.hip_entry
     def forward(self, x: torch.Tensor, return_dict: bool = False, eps: Optional[torch.Tensor] = None):
         mu, logvar = self.encode(x)
         if self.clamp_latent:

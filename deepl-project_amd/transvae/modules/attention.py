@@ -59,6 +59,7 @@ class RoPE2D(nn.Module):
         self._tabs = {}
         return super()._apply(fn, *a, **k)
 
+    @ops.hip_entry
     def forward(self, x: torch.Tensor, H: int, W: int) -> torch.Tensor:
         """Reference-style call on [B, heads, N, dim] (any float dtype); returns the same shape."""
         B, h, N, d = x.shape
@@ -109,6 +110,7 @@ class FlashAttentionWithRoPE(nn.Module):
         return fused.AttnBranchFn.apply(t, rms_weight, w, b, self.proj.weight, self.proj.bias, tab, B, H * W,
                                         self.num_heads, self.scale, rms_eps, self.norm_q.eps)
 
+    @ops.hip_entry
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Reference-style call: x [B, C, H, W] (already normalised by the caller) -> attention output."""
         B, C, H, W = x.shape

@@ -65,6 +65,7 @@ class ResBlock(nn.Module):
             skip = ops.linear(x.view(B * H * W, C), w, self.shortcut.bias).view(B, H, W, self.out_channels)
         return ops.conv(a, krsc(self.conv2), self.conv2.bias, skip, "c3s1")
 
+    @ops.hip_entry
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return nchw_call(self, x)
 
@@ -85,6 +86,7 @@ class RMSNorm(nn.Module):
     def forward_tokens(self, t: torch.Tensor) -> torch.Tensor:  # [T, C] bf16
         return (ops.rms_hat(t, self.eps).float() * self.weight).to(torch.bfloat16)
 
+    @ops.hip_entry
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() == 4:
             B, C, H, W = x.shape
@@ -125,5 +127,6 @@ class TransVAEBlock(nn.Module):
         t = self.ffn.forward_tokens(t, B, H, W, self.norm2.weight, self.norm2.eps)
         return t.view(B, H, W, C)
 
+    @ops.hip_entry
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return nchw_call(self, x)

@@ -53,6 +53,7 @@ class ConvFFN(nn.Module):
                                            c4.weight.view(hid, mid), c4.bias, self.proj_out.weight, self.proj_out.bias,
                                            B, H, W, rms_eps)
 
+    @ops.hip_entry
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Reference-style call on [B, C, H, W] (input already normalised)."""
         B, C, H, W = x.shape

@@ -43,6 +43,7 @@ class Downsample(nn.Module):
         return fused.DownsampleFn.apply(x, _krsc(self.main_path[0]), self.main_path[0].bias,
                                         _krsc(self.main_path[2]), self.main_path[2].bias, wdc, bdc)
 
+    @ops.hip_entry
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from .blocks import nchw_call
         return nchw_call(self, x)
@@ -70,6 +71,7 @@ class Upsample(nn.Module):
         return fused.UpsampleFn.apply(x, _krsc(self.main_path[1]), self.main_path[1].bias,
                                       _krsc(self.main_path[3]), self.main_path[3].bias, wdc, bdc)
 
+    @ops.hip_entry
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         from .blocks import nchw_call
         return nchw_call(self, x)

@@ -42,13 +42,24 @@ def micro_batches(n: int, micro: int):
 
 def vae_bench_loss(recon: torch.Tensor, x: torch.Tensor, mu: torch.Tensor, logvar: torch.Tensor,
                    kl_weight: float = 1e-8) -> torch.Tensor:
-    """L1 + kl_weight * KL: the closed-form terms of the reference loss
-    (R/transvae/losses/vae_loss.py:83-84,94-96).  KL is summed over the latent and averaged over
-    the batch; the clamp keeps exp() finite in fp32 (P/.../vae_loss.py:96-102 does the same)."""
+    """L1 + kl_weight * KL: the closed-form terms of the reference loss, in fp32.
+
+    R/transvae/losses/vae_loss.py:83-84 (L1 = mean |recon - target|) and :94-96 (KL summed over everything and divided
+    by batch * H_lat * W_lat, i.e. summed over the latent channels and averaged over batch and latent pixels).  logvar is
+    clamped to [-30, 20] first, as the bf16 trainer does before it calls the loss (R/train_2.py:316-318)."""
     l1 = (recon.float() - x.float()).abs().mean()
+    mu32 = mu.float()
     lv = logvar.float().clamp(-30.0, 20.0)
-    kl = -0.5 * torch.sum(1 + lv - mu.float().pow(2) - lv.exp()) / x.shape[0]
+    kl = -0.5 * torch.sum(1 + lv - mu32.pow(2) - lv.exp()) / (mu.shape[0] * mu.shape[2] * mu.shape[3])
     return l1 + kl_weight * kl
+
+
+def warmup_lr(base_lr: float, step: int, warmup_steps: int) -> float:
+    """Linear warm-up then constant: the LambdaLR of R/train_2.py:266-273 (factor step / warmup_steps while
+    step < warmup_steps, so the very first optimizer step runs at lr 0)."""
+    if warmup_steps > 0 and step < warmup_steps:
+        return base_lr * float(step) / float(max(1, warmup_steps))
+    return base_lr
 
 
 def wrap_ddp(model: nn.Module, device: Optional[torch.device], bucket_mb: int = 128) -> nn.Module:
@@ -70,15 +81,73 @@ def _packed_weight_cache(x: torch.Tensor):
     return contextlib.nullcontext()
 
 
+def global_grad_norm(params) -> torch.Tensor:
+    """L2 norm of all gradients as ONE device scalar (fp32), no host sync."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return torch.zeros(())
+    norms = torch._foreach_norm(grads, 2.0)
+    return torch.linalg.vector_norm(torch.stack([n.float() for n in norms]), 2.0)
+
+
+def clip_and_step(params, optimizer: torch.optim.Optimizer, grad_clip: Optional[float], counters: Optional[dict] = None):
+    """Global-norm clip (R/train.py:610-612) + optimizer step, with the reference trainer's non-finite guard
+    (R/train_2.py:328-338: a non-finite loss skips the step; a non-finite loss or activation gradient makes the gradient
+    norm non-finite, which is what is tested here) -- all on the device, no host sync:
+
+      * optimizers that accept the GradScaler protocol (`_step_supports_amp_scaling`: torch's fused AdamW, and
+        transvae.optim.FusedAdamW) receive `grad_scale = 1 / clip_coef` and `found_inf`: the un-scale IS the clip, done
+        inside the update kernel (no separate pass over the 4.2 GB of gradients), and the whole update is skipped when
+        found_inf is set;
+      * any other optimizer (CPU tests): gradients are multiplied by the coefficient, non-finite ones zeroed, and the
+        step is skipped through a host check.
+
+    counters (optional dict of device scalars): 'skipped' is incremented on a skipped step, 'grad_norm' holds the last norm.
+    Returns the gradient norm before clipping."""
+    params = [p for p in params if p.grad is not None]
+    if not params:
+        return None
+    fused_norm = getattr(optimizer, "fused_clip_step", None)
+    if fused_norm is not None:           # transvae.optim.FusedAdamW: norm, clip, guard and update in its own kernels
+        norm, found_inf = fused_norm(grad_clip)
+    else:
+        norm = global_grad_norm(params)
+        found_inf = (~torch.isfinite(norm)).float()
+        if grad_clip is not None and grad_clip > 0:
+            coef = torch.clamp(grad_clip / (norm + 1e-6), max=1.0)
+        else:
+            coef = torch.ones_like(norm)
+        coef = torch.where(found_inf > 0, torch.ones_like(coef), coef)
+        if getattr(optimizer, "_step_supports_amp_scaling", False):
+            optimizer.grad_scale = (1.0 / coef).reshape(())
+            optimizer.found_inf = found_inf.reshape(())
+            try:
+                optimizer.step()
+            finally:
+                optimizer.grad_scale = None
+                optimizer.found_inf = None
+        else:
+            if bool(found_inf):      # (host check: this branch is the CPU / unfused path)
+                optimizer.zero_grad(set_to_none=True)
+            else:
+                torch._foreach_mul_([p.grad for p in params], coef)
+                optimizer.step()
+    if counters is not None:
+        counters["skipped"] = counters.get("skipped", 0) + found_inf.reshape(())
+        counters["grad_norm"] = norm
+    return norm
+
+
 def train_step(ddp_model: nn.Module, optimizer: torch.optim.Optimizer, x_local: torch.Tensor, micro: int,
                forward_loss: Callable[[nn.Module, torch.Tensor], torch.Tensor], grad_clip: float = 1.0,
-               global_batch: Optional[int] = None) -> torch.Tensor:
+               global_batch: Optional[int] = None, counters: Optional[dict] = None) -> torch.Tensor:
     """One optimizer step over this rank's images.
 
     forward_loss(model, x_mb) returns the MEAN loss over x_mb.  Each micro-batch loss is weighted by
     count/global_batch * world_size so that, after DDP's gradient averaging, the result equals the
     gradient of the mean loss over the GLOBAL batch -- identical to a single-process full-batch step.
-    Returns the (detached) local weighted loss sum; no host sync happens here.
+    Returns the (detached) local weighted loss sum; no host sync happens here.  A step whose gradients are not
+    finite is skipped on the device (see clip_and_step); `counters['skipped']` counts them.
     """
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     n_local = x_local.shape[0]
@@ -95,7 +164,5 @@ def train_step(ddp_model: nn.Module, optimizer: torch.optim.Optimizer, x_local: 
                 loss = forward_loss(ddp_model, x_local[s:s + c]) * (c * world / global_batch)
                 loss.backward()
             total += loss.detach()
-    if grad_clip is not None and grad_clip > 0:
-        torch.nn.utils.clip_grad_norm_(ddp_model.parameters(), grad_clip)
-    optimizer.step()
+    clip_and_step(list(ddp_model.parameters()), optimizer, grad_clip, counters)
     return total

@@ -128,7 +128,8 @@ int tv_pack_weight(const float* src, void* dst, void* dst_t, int O, int T, int I
  * finalize kernel adds the partials in block order (no atomics => bit-reproducible).  `partials`
  * is scratch of tv_gn_partial_count(batch, hw, C) floats. */
 long long tv_gn_partial_count(int batch, int hw, int C);
-/* per-(b,channel) sums: stats[b][c][0]=sum x, [1]=sum x^2  (fp32) */
+/* per-(b,channel) sums about the pivot piv = x[b, pixel 0, c]: stats[b][c][0] = sum (x - piv), [1] = sum (x - piv)^2
+ * (fp32; tv_gn_silu_fwd merges the channels of a group with Chan's (mean, M2) update -- no E[x^2] - mean^2 cancellation) */
 int tv_gn_stats(const void* x, float* stats, float* partials, int batch, int hw, int C, void* stream);
 /* y = silu(groupnorm(x)); stats from tv_gn_stats; writes mean/rstd per (b,group) to mr[b][G][2] */
 int tv_gn_silu_fwd(const void* x, const float* stats, const float* gamma, const float* beta,

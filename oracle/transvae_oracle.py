@@ -225,39 +225,50 @@ def upsample(x: Tensor, sd: SD, p: str) -> Tensor:
 # ---------------------------------------------------------------------------
 # encoder / decoder / model
 # ---------------------------------------------------------------------------
-def encoder(x: Tensor, sd: SD, cfg: dict, p: str = "encoder.", use_rope: bool = True) -> Tensor:
-    """R/transvae/models/encoder.py:101-126 (2 CNN stages, then transformer stages)."""
-    depths = cfg["depths"]
-    hd = cfg.get("head_dim", 64)
-    h = F.conv2d(x, sd[p + "conv_in.weight"], sd[p + "conv_in.bias"], padding=1)
-    for i, depth in enumerate(depths):
-        for j in range(depth):
-            bp = f"{p}stages.{i}.{j}."
-            h = res_block(h, sd, bp) if i < 2 else transvae_block(h, sd, bp, hd, use_rope)
-        if i < len(depths) - 1:
-            h = downsample(h, sd, f"{p}downsamples.{i}.")
+def _tap(taps, key: str, h: Tensor) -> Tensor:
+    """taps: optional dict that receives every intermediate (precision attribution, tests/precision_report.py); a tap may
+    also REPLACE the tensor (taps['@' + key] = callable) so that a stage can be fed a chosen input."""
+    if taps is not None:
+        taps[key] = h.detach()
+        sub = taps.get("@" + key)
+        if sub is not None:
+            h = sub(h)
     return h
 
 
-def decoder(z: Tensor, sd: SD, cfg: dict, p: str = "decoder.", use_rope: bool = True) -> Tensor:
+def encoder(x: Tensor, sd: SD, cfg: dict, p: str = "encoder.", use_rope: bool = True, taps=None) -> Tensor:
+    """R/transvae/models/encoder.py:101-126 (2 CNN stages, then transformer stages)."""
+    depths = cfg["depths"]
+    hd = cfg.get("head_dim", 64)
+    h = _tap(taps, p + "conv_in", F.conv2d(x, sd[p + "conv_in.weight"], sd[p + "conv_in.bias"], padding=1))
+    for i, depth in enumerate(depths):
+        for j in range(depth):
+            bp = f"{p}stages.{i}.{j}."
+            h = _tap(taps, bp[:-1], res_block(h, sd, bp) if i < 2 else transvae_block(h, sd, bp, hd, use_rope))
+        if i < len(depths) - 1:
+            h = _tap(taps, f"{p}downsamples.{i}", downsample(h, sd, f"{p}downsamples.{i}."))
+    return h
+
+
+def decoder(z: Tensor, sd: SD, cfg: dict, p: str = "decoder.", use_rope: bool = True, taps=None) -> Tensor:
     """R/transvae/models/decoder.py:102-132 (mirror: transformer stages first)."""
     depths = cfg["depths"][::-1]
     hd = cfg.get("head_dim", 64)
     n = len(depths)
-    h = F.conv2d(z, sd[p + "conv_in.weight"], sd[p + "conv_in.bias"], padding=1)
+    h = _tap(taps, p + "conv_in", F.conv2d(z, sd[p + "conv_in.weight"], sd[p + "conv_in.bias"], padding=1))
     for i, depth in enumerate(depths):
         for j in range(depth):
             bp = f"{p}stages.{i}.{j}."
-            h = transvae_block(h, sd, bp, hd, use_rope) if i < n - 2 else res_block(h, sd, bp)
+            h = _tap(taps, bp[:-1], transvae_block(h, sd, bp, hd, use_rope) if i < n - 2 else res_block(h, sd, bp))
         if i < n - 1:
-            h = upsample(h, sd, f"{p}upsamples.{i}.")
+            h = _tap(taps, f"{p}upsamples.{i}", upsample(h, sd, f"{p}upsamples.{i}."))
     h = gn_silu(h, sd[p + "norm_out.weight"], sd[p + "norm_out.bias"])
     return F.conv2d(h, sd[p + "conv_out.weight"], sd[p + "conv_out.bias"], padding=1)
 
 
-def encode(x: Tensor, sd: SD, cfg: dict) -> Tuple[Tensor, Tensor]:
+def encode(x: Tensor, sd: SD, cfg: dict, taps=None) -> Tuple[Tensor, Tensor]:
     """R/transvae/models/transvae.py:170-184."""
-    h = encoder(x, sd, cfg)
+    h = encoder(x, sd, cfg, taps=taps)
     mu = F.conv2d(h, sd["conv_mu.weight"], sd["conv_mu.bias"], padding=1)
     logvar = F.conv2d(h, sd["conv_logvar.weight"], sd["conv_logvar.bias"], padding=1)
     return mu, logvar
@@ -272,28 +283,33 @@ def reparameterize(mu: Tensor, logvar: Tensor, eps: Tensor, clamp: bool = False)
     return mu + eps * torch.exp(0.5 * logvar)
 
 
-def decode(z: Tensor, sd: SD, cfg: dict) -> Tensor:
-    return decoder(z, sd, cfg)
+def decode(z: Tensor, sd: SD, cfg: dict, taps=None) -> Tensor:
+    return decoder(z, sd, cfg, taps=taps)
 
 
-def forward(x: Tensor, sd: SD, cfg: dict, eps: Tensor, clamp: bool = False):
+def forward(x: Tensor, sd: SD, cfg: dict, eps: Tensor, clamp: bool = False, taps=None):
     """R/transvae/models/transvae.py:213-242; clamp=True adds P/...:243-245."""
-    mu, logvar = encode(x, sd, cfg)
+    mu, logvar = encode(x, sd, cfg, taps)
     if clamp:
         mu = mu.clamp(-50, 50)
         logvar = logvar.clamp(-30, 20)
     z = reparameterize(mu, logvar, eps, clamp)
-    return decode(z, sd, cfg), mu, logvar
+    return decode(z, sd, cfg, taps), mu, logvar
 
 
-def bench_loss(recon: Tensor, x: Tensor, mu: Tensor, logvar: Tensor, kl_weight: float = 1e-8) -> Tensor:
+def bench_loss(recon: Tensor, x: Tensor, mu: Tensor, logvar: Tensor, kl_weight: float = 1e-8,
+               clamp_logvar: bool = False) -> Tensor:
     """The closed-form part of the reference loss used for the benchmark:
     L1 + kl_weight * KL  (R/transvae/losses/vae_loss.py:83-84,94-96).
 
-    KL = -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) / batch.
+    KL = -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) / (batch * H_lat * W_lat)   (vae_loss.py:94-95: the sum over
+    the latent CHANNELS stays, batch and latent pixels are averaged).  clamp_logvar=True clamps logvar to [-30, 20]
+    first, as the bf16 trainer does before calling the loss (R/train_2.py:316-318).
     """
     l1 = (recon - x).abs().mean()
-    kl = -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp()) / x.shape[0]
+    if clamp_logvar:
+        logvar = logvar.clamp(-30.0, 20.0)
+    kl = -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp()) / (mu.shape[0] * mu.shape[2] * mu.shape[3])
     return l1 + kl_weight * kl
 
 

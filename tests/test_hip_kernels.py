@@ -346,6 +346,30 @@ def test_groupnorm_silu(shape):
     assert rel(bd.grad, br.grad) < 1e-2
 
 
+def test_groupnorm_statistics_with_a_large_mean():
+    """|mean| >> std (a drifted residual stream): the one-pass E[x^2] - mean^2 form loses the variance to cancellation in
+    fp32; the kernels sum about a per-channel pivot and merge channels with Chan's update, so mean / rstd must agree with
+    a float64 two-pass computation.  Per-channel offsets differ inside a group (the merge term), 65 536 pixels per image."""
+    from transvae.hip import _lib as L
+    from transvae.hip import fused
+    B, H, W, Cc, G = 2, 256, 256, 64, 32
+    g = torch.Generator().manual_seed(0)
+    offs = 50.0 + 3.0 * torch.randn(Cc, generator=g)                      # mean / std ~ 100 at std 0.5 (bf16 ulp 0.25)
+    x = (0.5 * torch.randn(B, H, W, Cc, generator=g) + offs).to(BF)
+    xd = x.to(dev())
+    ga, be = torch.ones(Cc, device=dev()), torch.zeros(Cc, device=dev())
+    y, mr = fused.gn_silu_fwd(xd, ga, be, G, 1e-5)
+    xg = x.double().view(B, H * W, G, Cc // G)
+    mean = xg.mean(dim=(1, 3))
+    var = xg.var(dim=(1, 3), unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    mr = mr.cpu().double()
+    assert float((mr[..., 0] - mean).abs().max()) < 1e-4 * float(mean.abs().max())
+    assert float(((mr[..., 1] - rstd) / rstd).abs().max()) < 1e-3, float(((mr[..., 1] - rstd) / rstd).abs().max())
+    yref = F.silu(F.group_norm(x.double().permute(0, 3, 1, 2), G, eps=1e-5)).permute(0, 2, 3, 1)
+    assert rel(y, yref) < 1e-2
+
+
 @pytest.mark.parametrize("T,Cc", [(50, 64), (300, 384), (17, 1536), (9, 2560)])
 def test_rownorm(T, Cc):
     from transvae.hip import ops

@@ -104,3 +104,66 @@ def test_two_rank_gloo_step_equals_single_process():
     assert nosync_calls == 2 * 2          # 3 micro-batches per step: 2 without sync, the last one syncs
     for k, v in ref.state_dict().items():
         assert torch.allclose(torch.from_numpy(sd[k]), v, rtol=1e-4, atol=1e-6), k
+
+
+# ---- numerical guards of the train step (R/train_2.py:266-273, 316-318, 328-338; R/train.py:610-612) ------------
+def test_warmup_lr_follows_reference_lambda():
+    from transvae.parallel import warmup_lr
+    assert warmup_lr(1e-4, 0, 1000) == 0.0                      # LambdaLR factor step / warmup_steps at step 0
+    assert abs(warmup_lr(1e-4, 250, 1000) - 2.5e-5) < 1e-12
+    assert warmup_lr(1e-4, 1000, 1000) == 1e-4 and warmup_lr(1e-4, 5000, 1000) == 1e-4
+    assert warmup_lr(1e-4, 0, 0) == 1e-4                        # no warm-up
+
+
+def test_bench_loss_is_the_reference_formula():
+    """vae_loss.py:83-84,94-96 written out: L1 mean + 1e-8 * (-0.5 * sum(...)) / (B * H * W); equal to the oracle's."""
+    from oracle import transvae_oracle as O
+    from transvae.parallel import vae_bench_loss
+    g = torch.Generator().manual_seed(0)
+    recon, x = torch.randn(3, 3, 16, 16, generator=g), torch.rand(3, 3, 16, 16, generator=g)
+    mu, logvar = torch.randn(3, 4, 2, 2, generator=g) * 3, torch.randn(3, 4, 2, 2, generator=g) * 2
+    kl = -0.5 * torch.sum(1 + logvar - mu.pow(2) - logvar.exp())
+    kl = kl / (mu.shape[0] * mu.shape[2] * mu.shape[3])
+    want = torch.nn.functional.l1_loss(recon, x) + 1e-8 * kl
+    assert torch.allclose(vae_bench_loss(recon, x, mu, logvar), want, rtol=1e-6)
+    assert torch.allclose(O.bench_loss(recon, x, mu, logvar), want, rtol=1e-6)
+    # the clamp of train_2.py:316-318 keeps exp() finite
+    big = torch.full_like(logvar, 500.0)
+    assert torch.isfinite(vae_bench_loss(recon, x, mu, big)) and torch.isfinite(O.bench_loss(recon, x, mu, big, clamp_logvar=True))
+    assert not torch.isfinite(O.bench_loss(recon, x, mu, big))
+
+
+def test_clip_and_step_matches_torch_clip_and_skips_non_finite():
+    from transvae.parallel import clip_and_step
+    torch.manual_seed(0)
+    a, b = Net(), Net()
+    b.load_state_dict(a.state_dict())
+    x = torch.rand(4, 3, 8, 8)
+    oa = torch.optim.AdamW(a.parameters(), lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0)
+    ob = torch.optim.AdamW(b.parameters(), lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0)
+    (_loss(a, x) * 50).backward()
+    (_loss(b, x) * 50).backward()
+    counters = {}
+    n = clip_and_step(list(a.parameters()), oa, 1.0, counters)
+    n_ref = torch.nn.utils.clip_grad_norm_(b.parameters(), 1.0)
+    ob.step()
+    assert float(n) > 1.0 and abs(float(n) - float(n_ref)) < 1e-5 * float(n_ref)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7)
+    assert float(counters["skipped"]) == 0
+    # a non-finite gradient: the step is skipped, parameters and Adam moments are untouched, the next step is normal
+    before = {k: v.clone() for k, v in a.state_dict().items()}
+    m_before = [oa.state[p]["exp_avg"].clone() for p in a.parameters()]
+    oa.zero_grad()
+    _loss(a, x).backward()
+    next(a.parameters()).grad[0, 0, 0, 0] = float("nan")
+    clip_and_step(list(a.parameters()), oa, 1.0, counters)
+    assert float(counters["skipped"]) == 1
+    for k, v in a.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    for p, m0 in zip(a.parameters(), m_before):
+        assert torch.equal(oa.state[p]["exp_avg"], m0)
+    oa.zero_grad()
+    _loss(a, x).backward()
+    clip_and_step(list(a.parameters()), oa, 1.0, counters)
+    assert float(counters["skipped"]) == 1 and any(not torch.equal(v, before[k]) for k, v in a.state_dict().items())

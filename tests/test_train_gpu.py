@@ -1,0 +1,282 @@
+"""The train step around the HIP path on the GPU (`-m gpu`): several optimizer steps against the fp32 CPU oracle,
+the non-finite guard, the reference trainers' autocast call style, and the N>1 code path with the REAL model
+(two ranks over gloo sharing cuda:0 -- RCCL refuses two ranks per device; the DDP hooks, bucket views, no_sync and the
+fused autograd Functions are the same).
+
+Reference call pattern: R/train.py:557-646 (accumulate, clip, AdamW), R/train_2.py:266-273,303-338 (bf16 policy,
+logvar clamp, skip on non-finite), P/.../transvae.py:186-196,243-245 (clamps)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import filler
+from oracle import transvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def micro_model(**kw):
+    from transvae import TransVAE
+    m = TransVAE(config=dict(O.MICRO), variant="micro", compression_ratio=16, latent_dim=4, **kw)
+    m.load_state_dict(filler.fill_state_dict(O.state_dict_schema(O.MICRO, latent_dim=4)))
+    return m.to(DEV)
+
+
+def make_optimizer(params, kind, lr):
+    if kind == "torch":
+        return torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
+    from transvae.optim import FusedAdamW
+    return FusedAdamW(params, lr=lr, betas=(0.9, 0.95), weight_decay=0.0)
+
+
+def optimizer_kinds():
+    kinds = ["torch"]
+    try:
+        import transvae.optim  # noqa: F401
+        kinds.append("hip")
+    except ImportError:
+        pass
+    return kinds
+
+
+@pytest.mark.parametrize("kind", optimizer_kinds())
+def test_train_steps_follow_the_oracle(kind):
+    """10 optimizer steps of transvae.parallel.train_step (2 micro-batches per step, packed-weight cache on, clip 1.0,
+    AdamW lr 1e-4) on the micro model against the fp32 oracle + torch.optim.AdamW on the same weights, images and noise
+    stream.  bf16 tier: every step's loss within 1e-2 relative of the oracle's (measured ~1e-3), gradient norms within
+    5 %, the loss falls, nothing is skipped.  This is the test that clears the kernels of the round-1 NaN."""
+    from transvae.parallel import train_step, vae_bench_loss
+    steps, B, mb, lr = 10, 4, 2, 1e-4
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(B, 3, 64, 64, generator=g)
+    eps_all = torch.randn(steps, B, 4, 4, 4, generator=g)
+
+    # ---- oracle: fp32 CPU, one full batch per step
+    cfg = dict(O.MICRO)
+    sd = filler.fill_state_dict(O.state_dict_schema(cfg, latent_dim=4))
+    sd = {k: v.clone().requires_grad_(not k.endswith("inv_freq")) for k, v in sd.items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    opt_ref = torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.95), weight_decay=0.0)
+    ref_loss, ref_norm = [], []
+    for s in range(steps):
+        opt_ref.zero_grad()
+        recon, mu, logvar = O.forward(x, sd, cfg, eps_all[s], clamp=True)
+        loss = O.bench_loss(recon, x, mu, logvar, clamp_logvar=True)
+        loss.backward()
+        ref_norm.append(float(torch.nn.utils.clip_grad_norm_(params, 1.0)))
+        opt_ref.step()
+        ref_loss.append(float(loss.detach()))
+
+    # ---- HIP path: two micro-batches per step through train_step
+    m = micro_model(clamp_latent=True)
+    m.train()
+    opt = make_optimizer(m.parameters(), kind, lr)
+    xd = x.to(DEV)
+    counters = {}
+    got_loss, got_norm = [], []
+    for s in range(steps):
+        it = iter([eps_all[s, :mb].to(DEV), eps_all[s, mb:].to(DEV)])
+
+        def forward_loss(model, xb):
+            recon, mu, logvar = model(xb, eps=next(it))
+            return vae_bench_loss(recon, xb, mu, logvar)
+        got_loss.append(train_step(m, opt, xd, mb, forward_loss, 1.0, B, counters))
+        got_norm.append(counters["grad_norm"])
+    got_loss = [float(v) for v in got_loss]
+    got_norm = [float(v) for v in got_norm]
+    print("oracle loss", np.round(ref_loss, 4), "\nhip    loss", np.round(got_loss, 4))
+    print("oracle |g| ", np.round(ref_norm, 4), "\nhip    |g| ", np.round(got_norm, 4))
+    assert float(counters["skipped"]) == 0
+    assert all(np.isfinite(got_loss)) and got_loss[-1] < got_loss[0] - 0.05
+    for s in range(steps):
+        assert abs(got_loss[s] - ref_loss[s]) < 1e-2 * ref_loss[s], (s, got_loss[s], ref_loss[s])
+        assert abs(got_norm[s] - ref_norm[s]) < 5e-2 * ref_norm[s], (s, got_norm[s], ref_norm[s])
+    # after 10 AdamW steps the weights have moved by ~steps * lr per element; both runs moved the same way
+    moved, agree = 0.0, 0.0
+    p0 = filler.fill_state_dict(O.state_dict_schema(cfg, latent_dim=4))
+    for k, p in m.named_parameters():
+        d_hip = (p.detach().cpu().double() - p0[k].double()).flatten()
+        d_ref = (sd[k].detach().double() - p0[k].double()).flatten()
+        moved += float(d_ref.norm() ** 2)
+        agree += float((d_hip - d_ref).norm() ** 2)
+    assert agree / moved < 0.15 ** 2, (agree / moved) ** 0.5     # measured ~0.05 (sign-like Adam updates amplify rounding noise)
+
+
+@pytest.mark.parametrize("kind", optimizer_kinds())
+def test_non_finite_step_is_skipped_on_the_device(kind):
+    """R/train_2.py:328-338.  Without the P/ clamps a logvar of +1000 overflows exp(): loss and gradients are not finite;
+    the step must leave parameters and optimizer state untouched and count one skip -- and the same weights WITH the
+    clamps (the bench's configuration) step normally."""
+    from transvae.parallel import train_step, vae_bench_loss
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 3, 64, 64, generator=g).to(DEV)
+    eps = torch.randn(2, 4, 4, 4, generator=g).to(DEV)
+
+    def forward_loss(model, xb):
+        recon, mu, logvar = model(xb, eps=eps)
+        return vae_bench_loss(recon, xb, mu, logvar)
+    for clamp in (False, True):
+        m = micro_model(clamp_latent=clamp)
+        m.train()
+        opt = make_optimizer(m.parameters(), kind, 1e-3)
+        counters = {}
+        train_step(m, opt, x, 2, forward_loss, 1.0, 2, counters)          # a normal step first (creates the Adam state)
+        assert float(counters["skipped"]) == 0
+        with torch.no_grad():
+            m.conv_logvar.bias.add_(1000.0)
+        before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        loss = train_step(m, opt, x, 2, forward_loss, 1.0, 2, counters)
+        if clamp:
+            assert torch.isfinite(loss) and float(counters["skipped"]) == 0
+            assert any(not torch.equal(v, before[k]) for k, v in m.state_dict().items())
+        else:
+            assert not torch.isfinite(loss)
+            assert float(counters["skipped"]) == 1
+            for k, v in m.state_dict().items():
+                assert torch.equal(v, before[k]), k
+            with torch.no_grad():
+                m.conv_logvar.bias.sub_(1000.0)
+            loss = train_step(m, opt, x, 2, forward_loss, 1.0, 2, counters)   # and training resumes
+            assert torch.isfinite(loss) and float(counters["skipped"]) == 1
+            assert any(not torch.equal(v, before[k]) for k, v in m.state_dict().items())
+
+
+def test_forward_backward_under_autocast_equals_plain_call():
+    """The reference trainers wrap model(images) in torch.cuda.amp.autocast (R/train.py:589-593, R/train_2.py:303-312).
+    The path has its own precision policy, so the result must be bit-identical with and without autocast (the parameter
+    folds W @ b / W * g would otherwise turn bf16 and the fp32-bias check would fire)."""
+    x = filler.rand_input("micro.x", (2, 3, 64, 64)).to(DEV)
+    eps = filler.randn_input("micro.eps", (2, 4, 4, 4)).to(DEV)
+    outs = []
+    for amp in (False, True):
+        m = micro_model()
+        m.train()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            recon, mu, logvar = m(x, eps=eps)
+            mu2, _ = m.encode(x)
+            dec = m.decode(eps)
+        assert recon.dtype == torch.float32 and mu.dtype == torch.float32
+        (recon.float() - x).abs().mean().backward()
+        outs.append((recon.detach(), mu.detach(), mu2.detach(), dec.detach(),
+                     {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for k in a[4]:
+        ga, gb = a[4][k].double(), b[4][k].double()
+        assert float((ga - gb).norm()) <= 1e-5 * float(ga.norm()) + 1e-12, k     # weight gradients: fp32 atomics order
+
+
+def test_wrong_dtype_operands_raise_runtime_error():
+    from transvae.hip import ops
+    x = torch.randn(64, 64, device=DEV).to(torch.bfloat16)
+    w = torch.randn(64, 64, device=DEV)
+    with pytest.raises(RuntimeError, match="fp32"):
+        ops.linear(x, w, torch.zeros(64, device=DEV, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError, match="fp32 master"):
+        ops.linear(x, w.to(torch.bfloat16))
+    with pytest.raises(RuntimeError, match="bf16"):
+        ops.linear(x.float(), w)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_model_on_a_non_current_device():
+    """model.to('cuda:1') without torch.cuda.set_device(1): the entry points switch device themselves."""
+    from transvae import TransVAE
+    m = TransVAE(config=dict(O.MICRO), variant="micro", compression_ratio=16, latent_dim=4)
+    m.load_state_dict(filler.fill_state_dict(O.state_dict_schema(O.MICRO, latent_dim=4)))
+    x = filler.rand_input("micro.x", (2, 3, 64, 64))
+    eps = filler.randn_input("micro.eps", (2, 4, 4, 4))
+    assert torch.cuda.current_device() == 0
+    r0 = m.to("cuda:0")(x.to("cuda:0"), eps=eps.to("cuda:0"))[0].cpu()
+    r1 = m.to("cuda:1")(x.to("cuda:1"), eps=eps.to("cuda:1"))[0].cpu()
+    assert torch.equal(r0, r1)
+
+
+# ---- N > 1 with the real model ------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "deepl-project_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from transvae.parallel import shard_range, train_step, vae_bench_loss, wrap_ddp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = micro_model(clamp_latent=True)
+    m.train()
+    ddp = wrap_ddp(m, torch.device(DEV))
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(4, 3, 64, 64, generator=g).to(DEV)
+    eps = torch.randn(4, 4, 4, 4, generator=g).to(DEV)
+    s, c = shard_range(4, world, rank)
+    cursor = [s]
+
+    def forward_loss(model, xb):
+        e = eps[cursor[0]:cursor[0] + xb.shape[0]]
+        cursor[0] += xb.shape[0]
+        recon, mu, logvar = model(xb, eps=e)
+        return vae_bench_loss(recon, xb, mu, logvar)
+    counters = {}
+    loss = train_step(ddp, opt, x[s:s + c], 1, forward_loss, None, 4, counters)     # 2 micro-batches: no_sync + sync
+    t = loss.detach().clone()
+    dist.all_reduce(t)
+    grads = {k: p.grad.detach().float().cpu().numpy().copy() for k, p in m.named_parameters()}
+    if rank == 0:
+        q.put((float(t), float(counters["grad_norm"]), grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ddp_gradients_equal_the_single_process_step():
+    """World size 2 over gloo, both ranks on cuda:0, the real HIP micro model under DDP (bucket views, no_sync on the first
+    micro-batch): the averaged gradients equal those of one process running the whole batch (fp32 summation order only)."""
+    from transvae.parallel import train_step, vae_bench_loss
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    loss2, norm2, grads2 = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single process, same batch in one micro-batch
+    m = micro_model(clamp_latent=True)
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(4, 3, 64, 64, generator=g).to(DEV)
+    eps = torch.randn(4, 4, 4, 4, generator=g).to(DEV)
+
+    def forward_loss(model, xb):
+        recon, mu, logvar = model(xb, eps=eps)
+        return vae_bench_loss(recon, xb, mu, logvar)
+    counters = {}
+    loss1 = train_step(m, opt, x, 4, forward_loss, None, 4, counters)
+    assert abs(float(loss1) - loss2) < 1e-5 * abs(float(loss1))
+    assert abs(float(counters["grad_norm"]) - norm2) < 1e-4 * norm2
+    worst = 0.0
+    for k, p in m.named_parameters():
+        a, b = p.grad.detach().double().cpu(), torch.from_numpy(grads2[k]).double()
+        n = float(a.norm())
+        if n > 1e-12:
+            worst = max(worst, float((a - b).norm()) / n)
+    assert worst < 1e-4, worst
