@@ -150,6 +150,9 @@ def main():
                     help="alternate these resolutions step by step (BASELINE config 4: --resolutions 256 512 --global-batch 128)")
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--lr-warmup-steps", type=int, default=1000, help="linear warm-up of R/train_2.py:266-273 (0 = constant lr)")
+    ap.add_argument("--optimizer", choices=["hip", "torch"], default="hip",
+                    help="hip: transvae.optim.FusedAdamW (norm + clip + guard + AdamW + operand refresh in 4 launches); "
+                         "torch: torch.optim.AdamW(fused=True) behind the same guard")
     ap.add_argument("--no-clamp", action="store_true", help="model without the P/ clamps (for the guard's A/B only)")
     ap.add_argument("--global-batch", type=int, default=256)
     ap.add_argument("--micro-batch", type=int, default=64)
@@ -194,7 +197,11 @@ def main():
     init_scaled_(model, seed=0)
     model.train()
     ddp = wrap_ddp(model, dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
+    if args.optimizer == "hip":
+        from transvae.optim import FusedAdamW
+        opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0, fused=True)
 
     start, count = shard_range(args.global_batch, world, rank)
     gen = torch.Generator(device=dev)
@@ -283,7 +290,8 @@ def main():
                        "parallelism": f"dp{world}",
                        "weights": "random fan-in scaled", "loss": "L1 + 1e-8 KL (vae_loss.py:83-84,94-96)",
                        "numerics": "P/ clamps on mu/logvar, skip-on-non-finite guard",
-                       "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps},
+                       "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps,
+                       "optimizer": "transvae.optim.FusedAdamW (HIP multi-tensor)" if args.optimizer == "hip" else "torch.optim.AdamW(fused)"},
             "final_loss": round(final_loss, 5),
             "losses": [round(float(v), 5) for v in lt],
             "skipped_steps": int(skipped),

@@ -59,6 +59,11 @@ SIGNATURES = {
     "tv_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "tv_im2col3x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "tv_pool2x2_sum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "tv_opt_chunk_elems": (_I, []),
+    "tv_opt_grad_norm": (_I, [_P, _P, _I, _P, _P, _F, _F, _F, _I, _P]),
+    "tv_opt_adamw": (_I, [_P, _P, _I, _P, _F, _F, _F, _F, _F, _P]),
+    "tv_opt_cast_shadows": (_I, [_P, _P, _I, _P]),
+    "tv_pack_weight_multi": (_I, [_P, _I, _LL, _P]),
 }
 
 _lib = None

@@ -92,18 +92,101 @@ def packed_weight_cache():
         _pack_cache = prev
 
 
+# ---- bf16 operands owned by transvae.optim.FusedAdamW -------------------------------------------------------------
+# The optimizer writes a bf16 copy of every weight in its update pass (same element order as the fp32 master: for conv
+# weights in channels_last memory that IS the forward operand [Cout, KH*KW, Cin]) and refreshes every transposed
+# (data-gradient) operand that has been asked for in one multi-tensor launch after each step.  An entry is valid while
+# the parameter's autograd version and storage are the ones recorded at the last refresh: load_state_dict, init code or
+# any other in-place update bumps the version and the operands fall back to per-call packing until the optimizer's next
+# step.  (Updates through `param.data` bypass the version counter -- the usual caveat of `.data`.)
+class _ParamOperands:
+    __slots__ = ("ref", "shadow", "version", "ptr", "forms")
+
+    def __init__(self, p, shadow):
+        import weakref
+        self.ref = weakref.ref(p)
+        self.shadow = shadow
+        self.version = p._version
+        self.ptr = p.data_ptr()
+        self.forms = {}          # (element offset, O, T, I, flip) -> bf16 [I, T, O]
+
+
+_param_operands = {}   # id(param) -> _ParamOperands
+
+
+def register_param_shadows(params, shadows: dict):
+    for p in params:
+        sh = shadows.get(id(p))
+        if sh is not None:
+            _param_operands[id(p)] = _ParamOperands(p, sh)
+
+
+def _operands_of(base):
+    ent = _param_operands.get(id(base))
+    if ent is None:
+        return None
+    if ent.ref() is not base:
+        del _param_operands[id(base)]
+        return None
+    if ent.version != base._version or ent.ptr != base.data_ptr():
+        return None
+    return ent
+
+
+def refresh_param_operands(params):
+    """After FusedAdamW's update: the bf16 copies are fresh; re-derive every registered transposed operand from them in
+    one launch and record the parameters' versions."""
+    forms = []
+    keep = []
+    total = 0
+    for p in params:
+        ent = _param_operands.get(id(p))
+        if ent is None or ent.ref() is not p or ent.ptr != p.data_ptr():
+            continue
+        ent.version = p._version
+        flat = ent.shadow.as_strided((p.numel(),), (1,))
+        for (off, O, T, I, flip), dst in ent.forms.items():
+            forms.append((flat.data_ptr() + 2 * off, dst.data_ptr(), O | (T << 32), I | (int(flip) << 32), total))
+            total += ((O + 63) // 64) * ((I + 63) // 64) * T
+    if not forms:
+        return
+    dev = params[0].device
+    host = torch.tensor(forms, dtype=torch.int64).pin_memory()
+    tab = host.to(dev, non_blocking=True)
+    L.check(L.load().tv_pack_weight_multi(_p(tab), len(forms), total, _stream()), "tv_pack_weight_multi")
+    _refresh_keep[0] = (host, tab)
+
+
+_refresh_keep = [None]
+
+
 def pack_weight(w: torch.Tensor, want_fwd: bool, want_t: bool, flip: bool):
     """w: fp32 [O, T, I] contiguous -> (bf16 [O,T,I] | None, bf16 [I,T,O] | None)."""
     O, T, I = w.shape
     _require(w.dtype == torch.float32 and w.is_contiguous(), "pack_weight needs a contiguous fp32 [O, T, I] tensor")
+    base = w._base if w._base is not None else w
+    is_param = isinstance(base, torch.nn.Parameter)
+    if is_param:
+        ent = _operands_of(base)
+        if ent is not None:          # operands kept current by the optimizer: no kernel here
+            off = (w.data_ptr() - base.data_ptr()) // 4
+            if 0 <= off and off + O * T * I <= base.numel():
+                d = ent.shadow.as_strided((O, T, I), (T * I, I, 1), off) if want_fwd else None
+                dt = None
+                if want_t:
+                    fk = (off, O, T, I, bool(flip))
+                    dt = ent.forms.get(fk)
+                    if dt is None:   # first request: pack once here, the optimizer refreshes it from now on
+                        dt = torch.empty((I, T, O), dtype=BF16, device=w.device)
+                        L.check(L.load().tv_pack_weight(_p(w), None, _p(dt), O, T, I, int(flip), _stream()), "tv_pack_weight")
+                        ent.forms[fk] = dt
+                return d, dt
     key = None
-    if _pack_cache is not None:
-        base = w._base if w._base is not None else w
-        if isinstance(base, torch.nn.Parameter):
-            key = (id(base), base._version, w.data_ptr(), O, T, I, want_fwd, want_t, flip)
-            hit = _pack_cache.get(key)
-            if hit is not None:
-                return hit
+    if _pack_cache is not None and is_param:
+        key = (id(base), base._version, w.data_ptr(), O, T, I, want_fwd, want_t, flip)
+        hit = _pack_cache.get(key)
+        if hit is not None:
+            return hit
     d = torch.empty((O, T, I), dtype=BF16, device=w.device) if want_fwd else None
     dt = torch.empty((I, T, O), dtype=BF16, device=w.device) if want_t else None
     lib = L.load()

@@ -181,6 +181,44 @@ int tv_im2col3x3(const float* src, void* dst, int B, int C, int H, int W, int Kp
 /* dst[b,y,x,c] = sum of the 2x2 block of src[b,2y+dy,2x+dx,c]  (adjoint of nearest x2) */
 int tv_pool2x2_sum(const void* src, void* dst, int B, int H, int W, int C, void* stream);
 
+/* Train-step glue around the path ------------------------------------------------------------------
+ * Multi-tensor AdamW with the global-norm clip and the non-finite guard on the device, replacing the caller pattern
+ *   clip_grad_norm_(model.parameters(), 1.0); optimizer.step()        (R/train.py:610-618, AdamW at :681-687)
+ *   "skip the step when the loss is not finite"                       (R/train_2.py:328-338)
+ * in two launches, plus one launch that refreshes every bf16 operand of the next forward / backward. */
+typedef struct tv_opt_tensor {
+    float* param;        /* fp32 master weights, updated in place */
+    const float* grad;   /* fp32 gradient (same element order as param) */
+    float* exp_avg;      /* Adam first moment  (fp32, updated in place) */
+    float* exp_avg_sq;   /* Adam second moment (fp32, updated in place) */
+    void* shadow_bf16;   /* optional: bf16 copy of param written by the update (NULL = none) */
+    long long numel;
+} tv_opt_tensor;
+/* elements handled by one workgroup; chunk table = int pairs (tensor index, chunk index inside the tensor) */
+int tv_opt_chunk_elems(void);
+/* ctrl: 8 device floats owned by the caller, persistent across steps:
+ *   [0] step count t   [1] gradient L2 norm   [2] clip coefficient   [3] 1 if this step is skipped (non-finite norm)
+ *   [4] skipped steps so far   [5] 1 - beta1^t   [6] sqrt(1 - beta2^t)
+ * Computes the global norm over all gradients (partials: n_chunks floats of scratch; fixed-order, bit-reproducible),
+ * coef = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: no clipping), advances t unless the norm is non-finite.
+ * compute_norm = 0 skips the reduction (norm reported as 0, never skipped). */
+int tv_opt_grad_norm(const tv_opt_tensor* table_dev, const int* chunks_dev, int n_chunks, float* partials,
+                     float* ctrl, float max_norm, float beta1, float beta2, int compute_norm, void* stream);
+/* AdamW update of every tensor in the table with g * ctrl[2] as the gradient; no-op when ctrl[3] != 0 */
+int tv_opt_adamw(const tv_opt_tensor* table_dev, const int* chunks_dev, int n_chunks, const float* ctrl,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+/* shadow_bf16 = (bf16) param for every tensor that has one (first fill) */
+int tv_opt_cast_shadows(const tv_opt_tensor* table_dev, const int* chunks_dev, int n_chunks, void* stream);
+/* every transposed operand in one launch: src bf16 [O,T,I] -> dst_t bf16 [I,T',O] (T' reversed if flip);
+ * tile_start = exclusive prefix sum of ceil(O/64)*ceil(I/64)*T over the forms */
+typedef struct tv_pack_form {
+    const void* src;
+    void* dst_t;
+    int O, T, I, flip;
+    long long tile_start;
+} tv_pack_form;
+int tv_pack_weight_multi(const tv_pack_form* forms_dev, int n_forms, long long total_tiles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

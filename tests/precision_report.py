@@ -90,7 +90,7 @@ def run(name):
     for k in keys:
         cum = l2(nchw(hip_taps[k]), ref_taps[k])
         local = None
-        if prev is not None:       # one block, oracle input (bf16-rounded) -> its own error
+        if prev is not None and not k.endswith("conv_in"):       # one block, oracle input (bf16-rounded) -> its own error
             with torch.no_grad():
                 y = block_of(m, k).forward_nhwc(nhwc16(ref_taps[prev], "cuda"))
             local = l2(nchw(y), ref_taps[k])
@@ -98,9 +98,7 @@ def run(name):
             local = cum
         out["stages"].append({"at": k, "cum": cum, "local": local, "shape": list(ref_taps[k].shape)})
         print(f"  {k:28s} cum {cum:.4f}" + (f"   local {local:.4f}" if local is not None else ""))
-        prev = k if not k.endswith("decoder.conv_in") else k
-        if k == keys[-1]:
-            break
+        prev = k
     # the decoder's first tap follows z, not the encoder's last tap: recompute its local error from the oracle's z
     for s in out["stages"]:
         if s["at"] == "decoder.conv_in":

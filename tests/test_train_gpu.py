@@ -169,7 +169,9 @@ def test_forward_backward_under_autocast_equals_plain_call():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     for k in a[4]:
         ga, gb = a[4][k].double(), b[4][k].double()
-        assert float((ga - gb).norm()) <= 1e-5 * float(ga.norm()) + 1e-12, k     # weight gradients: fp32 atomics order
+        # weight gradients are summed with fp32 atomics (order noise; biases that feed a GroupNorm have an exactly-zero
+        # gradient in exact arithmetic, so what they hold IS that noise)
+        assert float((ga - gb).norm()) <= 1e-4 * float(ga.norm()) + 1e-8, k
 
 
 def test_wrong_dtype_operands_raise_runtime_error():
@@ -280,3 +282,93 @@ def test_two_rank_ddp_gradients_equal_the_single_process_step():
         if n > 1e-12:
             worst = max(worst, float((a - b).norm()) / n)
     assert worst < 1e-4, worst
+
+
+# ---- transvae.optim.FusedAdamW against torch.optim.AdamW ------------------------------------------------
+def test_fused_adamw_matches_torch_adamw_and_clip():
+    """Five steps on tensors of awkward sizes (a 70 001-element vector spanning two chunks, channels_last 4-D weights, a
+    gradient that is a 4-byte-aligned view into a flat bucket like DDP's), weight decay on, clip active: parameters and
+    moments equal torch.optim.AdamW + clip_grad_norm_ to fp32 rounding; the returned norm equals torch's."""
+    from transvae.optim import FusedAdamW
+    g = torch.Generator().manual_seed(0)
+    shapes = [(70001,), (33,), (64, 32, 3, 3), (96, 64), (7, 5, 1, 1)]
+
+    def make():
+        ps = []
+        for s in shapes:
+            t = torch.randn(s, generator=torch.Generator().manual_seed(len(s) * 100 + s[0])).to(DEV)
+            if len(s) == 4:
+                t = t.contiguous(memory_format=torch.channels_last)
+            ps.append(torch.nn.Parameter(t))
+        return ps
+    pa, pb = make(), make()
+    oa = FusedAdamW(pa, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    ob = torch.optim.AdamW(pb, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    for step in range(5):
+        bucket = torch.randn(sum(p.numel() for p in pa) + 1, generator=g).to(DEV) * (5.0 if step % 2 == 0 else 0.01)
+        off = 1                                      # odd element offset: 4-byte aligned views
+        for a, b in zip(pa, pb):
+            gv = bucket[off:off + a.numel()]
+            off += a.numel()
+            a.grad = gv.as_strided(a.shape, a.stride()) if a.dim() == 4 else gv.view(a.shape)
+            b.grad = a.grad.clone()
+        norm, skipped = oa.fused_clip_step(1.0)
+        ref_norm = torch.nn.utils.clip_grad_norm_(pb, 1.0)
+        ob.step()
+        assert float(skipped) == 0 and abs(float(norm) - float(ref_norm)) < 1e-5 * float(ref_norm)
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (step, tuple(a.shape), float((a - b).abs().max()))
+            assert torch.allclose(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"], rtol=1e-5, atol=1e-9)
+            assert torch.allclose(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    # state_dict interchange (the reference checkpoint's optimizer_state_dict, R/train.py:753-769)
+    sd = oa.state_dict()
+    assert float(sd["state"][0]["step"]) == 5 and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    ob2 = torch.optim.AdamW(pb, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    ob2.load_state_dict(sd)
+    oa2 = FusedAdamW(pa, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    oa2.load_state_dict(ob.state_dict())
+    for a, b in zip(pa, pb):
+        a.grad = torch.ones_like(a)
+        b.grad = torch.ones_like(b)
+    oa2.fused_clip_step(None)
+    ob2.step()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+
+
+def test_fused_adamw_keeps_the_bf16_operands_current():
+    """After a step the operands served by ops.pack_weight (forward = the optimizer's bf16 copy, transposed = refreshed by
+    tv_pack_weight_multi) equal a fresh tv_pack_weight of the updated fp32 weight, without any per-call pack kernel; an
+    outside in-place update invalidates them."""
+    from transvae.hip import ops
+    from transvae.optim import FusedAdamW
+    w = torch.nn.Parameter(torch.randn(96, 64, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last))
+    lin = torch.nn.Parameter(torch.randn(130, 72, device=DEV))
+    opt = FusedAdamW([w, lin], lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0)
+
+    def views():
+        return w.permute(0, 2, 3, 1).view(96, 9, 64), lin.view(130, 1, 72)
+
+    def fresh(v, flip):
+        d = torch.empty(v.shape, dtype=torch.bfloat16, device=DEV)
+        dt = torch.empty((v.shape[2], v.shape[1], v.shape[0]), dtype=torch.bfloat16, device=DEV)
+        from transvae.hip import _lib as L
+        L.check(L.load().tv_pack_weight(ops._p(v.contiguous()), ops._p(d), ops._p(dt), v.shape[0], v.shape[1], v.shape[2], int(flip),
+                                        ops._stream()), "tv_pack_weight")
+        return d, dt
+    for it in range(3):
+        vw, vl = views()
+        d1, t1 = ops.pack_weight(vw, True, True, True)
+        d2, t2 = ops.pack_weight(vl, True, True, False)
+        for (d, t), (v, flip) in (((d1, t1), (vw, True)), ((d2, t2), (vl, False))):
+            rd, rt = fresh(v.detach(), flip)
+            assert torch.equal(d, rd) and torch.equal(t, rt), it
+        assert d1.data_ptr() == opt._shadow[id(w)].data_ptr()          # served from the optimizer's copy
+        w.grad = torch.randn_like(w)
+        lin.grad = torch.randn_like(lin)
+        opt.fused_clip_step(1.0)
+    with torch.no_grad():
+        w.mul_(2.0)                                                      # someone else touches the weight
+    d, t = ops.pack_weight(views()[0], True, True, True)
+    rd, rt = fresh(views()[0].detach(), True)
+    assert torch.equal(d, rd) and torch.equal(t, rt) and d.data_ptr() != opt._shadow[id(w)].data_ptr()
