@@ -257,5 +257,141 @@ def main():
         np.linalg.norm(md["mu_bf16"] - md["mu"]) / np.linalg.norm(md["mu"])))
 
 
+LARGE_GRAD_KEYS = [
+    "encoder.conv_in.weight", "encoder.stages.0.0.conv1.weight", "encoder.stages.1.2.norm2.weight",
+    "encoder.downsamples.0.main_path.2.weight", "encoder.stages.2.0.attn.to_q.weight", "encoder.stages.2.0.attn.norm_k.bias",
+    "encoder.stages.2.1.ffn.proj_in.weight", "encoder.stages.4.5.ffn.conv.2.weight", "encoder.downsamples.3.dc_conv.weight",
+    "conv_mu.weight", "conv_logvar.weight", "decoder.conv_in.weight", "decoder.stages.0.0.ffn.conv.2.weight",
+    "decoder.stages.0.3.attn.proj.weight", "decoder.stages.2.2.attn.to_q.weight", "decoder.upsamples.3.main_path.1.weight",
+    "decoder.upsamples.0.dc_conv.weight", "decoder.stages.4.2.conv2.weight", "decoder.norm_out.weight", "decoder.conv_out.weight",
+]
+
+
+def large():
+    """BASELINE config 2's model at full size (TransVAE-Large f16d32, 256x256), ONE image, forward + backward through the
+    reference on the CPU (fp32), filler weights: output summaries, norms and 256 sampled elements of 20 named gradients
+    (N = 4096 attention projections, 1536-wide 3x3 FFN convs, stem, heads, DC paths), and the deviation of the reference's
+    OWN bf16-autocast run from its fp32 run on the same tensors (the yardstick of the bf16 tier)."""
+    import yaml
+    R = import_reference()
+    with open(REF + "/configs/transvae_large_f16d32.yaml") as f:
+        lcfg = yaml.safe_load(f)["model"]
+    model = R["TransVAE"](config=lcfg, variant="large", compression_ratio=16, latent_dim=32)
+    load_filled(model, "")
+    x = filler.rand_input("large.x", (1, 3, 256, 256))
+    eps = filler.randn_input("large.eps", (1, 32, 16, 16))
+    orig = torch.randn_like
+    out = {}
+
+    def run(autocast):
+        model.zero_grad()
+        torch.randn_like = lambda t, **kw: eps.to(t.dtype)
+        try:
+            if autocast:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    o = model(x, return_dict=True)
+            else:
+                o = model(x, return_dict=True)
+        finally:
+            torch.randn_like = orig
+        loss = O.bench_loss(o["reconstruction"].float(), x, o["mu"].float(), o["logvar"].float())
+        loss.backward()
+        params = dict(model.named_parameters())
+        return ({k: o[k].detach().float().clone() for k in ("reconstruction", "mu", "logvar")}, float(loss),
+                {k: params[k].grad.detach().clone() for k in LARGE_GRAD_KEYS})
+    import time
+    t0 = time.time()
+    o32, loss32, g32 = run(False)
+    print("large fp32 fwd+bwd %.1f s, loss %.5f" % (time.time() - t0, loss32), flush=True)
+    out["loss"] = np.asarray(loss32)
+    for nm, t in (("recon", o32["reconstruction"]), ("mu", o32["mu"]), ("logvar", o32["logvar"])):
+        for kk, vv in summarize(t[0], 256).items():
+            out[f"{nm}.{kk}"] = np.asarray(vv)
+        out[f"{nm}.l2"] = np.asarray(float(t.double().norm()))
+    for k, g in g32.items():
+        flat = g.flatten()
+        gi = torch.Generator().manual_seed(zlib_crc(k))
+        idx = torch.randperm(flat.numel(), generator=gi)[:256]
+        out[f"g:{k}.idx"] = idx.numpy()
+        out[f"g:{k}.val"] = flat[idx].numpy()
+        out[f"g:{k}.l2"] = np.asarray(float(flat.double().norm()))
+    t0 = time.time()
+    o16, loss16, g16 = run(True)
+    print("large bf16-autocast fwd+bwd %.1f s" % (time.time() - t0), flush=True)
+    dev = {}
+    for nm, key in (("recon", "reconstruction"), ("mu", "mu"), ("logvar", "logvar")):
+        dev[nm] = float((o16[key].double() - o32[key].double()).norm() / o32[key].double().norm())
+    for k in LARGE_GRAD_KEYS:
+        n = float(g32[k].double().norm())
+        dev["g:" + k] = float((g16[k].double() - g32[k].double()).norm() / n) if n > 1e-12 else 0.0
+    print("reference bf16-autocast deviation at Large:", {k: round(v, 4) for k, v in dev.items()})
+    np.savez_compressed(os.path.join(OUT, "large_one_image.npz"), **out)
+    with open(os.path.join(OUT, "large_ref_bf16_autocast.json"), "w") as f:
+        json.dump(dev, f, indent=0)
+
+
+def extra():
+    """The reference's own bf16-autocast deviation (forward outputs + first / last layer gradients) on the two small
+    configurations that tests/test_model_gpu.py checks against the oracle without a golden: the micro model at the
+    non-square 96 x 160 resolution and the compression-ratio-8 (four-stage) layout.  Inputs are the tests' own seeds."""
+    res = {}
+    R = import_reference()
+    orig = torch.randn_like
+
+    def run(model, x, eps, autocast):
+        model.zero_grad()
+        torch.randn_like = lambda t, **kw: eps.to(t.dtype)
+        try:
+            if autocast:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    o = model(x, return_dict=True)
+            else:
+                o = model(x, return_dict=True)
+        finally:
+            torch.randn_like = orig
+        O.bench_loss(o["reconstruction"].float(), x, o["mu"].float(), o["logvar"].float()).backward()
+        ps = dict(model.named_parameters())
+        return ({k: o[k].detach().float().clone() for k in ("reconstruction", "mu", "logvar")},
+                {k: ps[k].grad.detach().clone() for k in ("decoder.conv_out.weight", "encoder.conv_in.weight")})
+
+    def dev(model, x, eps):
+        o32, g32 = run(model, x, eps, False)
+        o16, g16 = run(model, x, eps, True)
+        d = {nm: float((o16[k].double() - o32[k].double()).norm() / o32[k].double().norm())
+             for nm, k in (("recon", "reconstruction"), ("mu", "mu"), ("logvar", "logvar"))}
+        for k in g32:
+            d["g:" + k] = float((g16[k].double() - g32[k].double()).norm() / g32[k].double().norm())
+        return d
+    # micro @ 96 x 160 (test_micro_model_nonsquare_against_oracle: generator seed 7)
+    cfg = dict(O.MICRO)
+    m = R["TransVAE"](config=cfg, variant="micro", compression_ratio=16, latent_dim=4)
+    load_filled(m, "")
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(1, 3, 96, 160, generator=g)
+    eps = torch.randn(1, 4, 6, 10, generator=g)
+    res["micro_96x160"] = dev(m, x, eps)
+    # compression ratio 8 (test_f8_style_config_against_oracle: filler keyed on the state-dict keys, generator seed 11)
+    cfg8 = dict(depths=[1, 1, 1, 1], base_dims=[32, 64, 64, 128], mlp_ratio=1.0, head_dim=64)
+    m8 = R["TransVAE"](config=cfg8, variant="micro8", compression_ratio=8, latent_dim=4)
+    load_filled(m8, "")
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(2, 3, 64, 64, generator=g)
+    eps = torch.randn(2, 4, 8, 8, generator=g)
+    res["f8_micro"] = dev(m8, x, eps)
+    print(json.dumps(res, indent=1))
+    with open(os.path.join(OUT, "ref_bf16_autocast_extra.json"), "w") as f:
+        json.dump(res, f, indent=0)
+
+
+def zlib_crc(k: str) -> int:
+    import zlib
+    return zlib.crc32(k.encode()) & 0x7FFFFFFF
+
+
 if __name__ == "__main__":
-    main()
+    if "--large" in sys.argv:      # 1.05 B parameters through the reference on the CPU: minutes, ~30 GB
+        large()
+    elif "--extra" in sys.argv:
+        extra()
+    else:
+        main()

@@ -7,11 +7,13 @@ Two references, same seeded weights / inputs (oracle/filler.py):
 The HIP path stores activations in bf16 (fp32 accumulate).  Tolerances, all relative L2:
   * single modules (one block deep): BASELINE's bf16 tier, 1e-2 on outputs; 3e-2 on gradients
     (twice as many bf16 roundings on the way)
-  * whole models (30-100 ops deep): bf16 rounding accumulates; the yardstick is the reference's OWN
-    bf16 tier -- its bf16-autocast forward deviates from its fp32 forward by 2.0e-2 / 1.2e-2
-    (micro recon / mu) and 2.5-3.2e-2 / 1.3e-2 (tiny, BASELINE config 1), numbers stored in the
-    goldens.  We require  err <= max(1e-2, 1.25 * that deviation)  and measure 1.7e-2 / 1.0e-2
-    (micro) and 2.7e-2 / 1.2e-2 (tiny) -- see tests/precision_report.py.
+  * whole models (30-100 ops deep): bf16 rounding accumulates (every block rounds its output once: ~3.5e-3 per block,
+    growing like the square root of the depth -- profiles/r02_precision_attribution.json); the yardstick is the
+    reference's OWN bf16 tier -- its bf16-autocast forward deviates from its fp32 forward by 2.0e-2 / 1.2e-2 / 1.6e-2
+    (micro recon / mu / logvar), 2.5-3.2e-2 / 1.3e-2 (tiny, BASELINE config 1) and 2.4e-2 / 1.4e-2 / 1.6e-2 (Large),
+    numbers minted by oracle/make_goldens.py and stored in the goldens.  We require
+    err <= max(1e-2, 1.0 * that deviation)  (gradients: max(3e-2, 1.5 x), one bf16 run is one draw of the noise)
+    and measure 1.7e-2 / 1.1e-2 / 1.3e-2 (micro) and 1.4e-2 / 1.1e-2 / 1.1e-2 (Large) -- tests/precision_report.py.
 Activations are bit-reproducible run to run (GroupNorm reductions are ordered, attention has no
 atomics); weight gradients are summed with fp32 atomics (order noise ~1e-7), so equalities between
 runs are checked to tolerance.
@@ -131,7 +133,7 @@ def test_micro_model_against_reference_golden(golden_dir):
     with torch.no_grad():
         mu, logvar = m.encode(x)
         assert mu.shape == (2, 4, 4, 4) and mu.dtype == torch.float32
-        tol = {k: max(1e-2, 1.25 * l2rel(g[k + "_bf16"], g[k])) for k in ("recon", "mu", "logvar")}
+        tol = {k: max(1e-2, 1.0 * l2rel(g[k + "_bf16"], g[k])) for k in ("recon", "mu", "logvar")}
         assert l2rel(mu, g["mu"]) < tol["mu"] and l2rel(logvar, g["logvar"]) < tol["logvar"]
         assert l2rel(m.decode(z_in), g["dec_z"]) < tol["recon"]
         assert l2rel(m.decoder(z_in), g["decoder_direct"]) < tol["recon"]   # P/generate_images.py:100-105 call style
@@ -168,11 +170,22 @@ def test_micro_model_against_reference_golden(golden_dir):
             assert err < max(3e-2, 1.5 * ref16[k[2:]]["l2rel"]), (k, err, ref16[k[2:]]["l2rel"])
 
 
+def _extra_ref16():
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_bf16_autocast_extra.json")) as f:
+        return json.load(f)
+
+
+def _large_ref16():
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_ref_bf16_autocast.json")) as f:
+        return json.load(f)
+
+
 def test_micro_model_nonsquare_against_oracle():
     """Non-square, non-power-of-two resolution (96 x 160: token grids 6x10 .. 96x160) against the fp32 oracle on the same
     weights and noise: exercises the division-based index paths, halo tiles that are not a power of two wide, ragged
     attention key blocks and the polyphase / parity convolutions at odd cell counts.  Tolerances: the bf16 tier of the
-    64 x 64 golden test above (outputs 1.25 x, gradients 1.5 x the reference's own bf16-autocast deviation there)."""
+    64 x 64 golden test (outputs 1.0 x, gradients 1.5 x the reference's own bf16-autocast deviation on exactly these
+    inputs, tests/golden/ref_bf16_autocast_extra.json)."""
     m = micro_model()
     cfg = dict(O.MICRO)
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
@@ -185,10 +198,14 @@ def test_micro_model_nonsquare_against_oracle():
     r_ref, mu_ref, lv_ref = O.forward(x, ref_sd, cfg, eps)
     O.bench_loss(r_ref, x, mu_ref, lv_ref).backward()
     assert recon.shape == x.shape and mu.shape == (1, 4, 6, 10)
-    assert l2rel(recon, r_ref) < 2.5e-2 and l2rel(mu, mu_ref) < 1.5e-2 and l2rel(logvar, lv_ref) < 2e-2
+    ref16 = _extra_ref16()["micro_96x160"]     # the reference's own bf16-autocast deviation on exactly these inputs
+    errs = {"recon": l2rel(recon, r_ref), "mu": l2rel(mu, mu_ref), "logvar": l2rel(logvar, lv_ref)}
+    print("micro 96x160 rel-L2 vs oracle:", errs, "reference bf16:", {k: ref16[k] for k in errs})
+    for k, e in errs.items():
+        assert e < max(1e-2, 1.0 * ref16[k]), (k, e, ref16[k])
     params = dict(m.named_parameters())
-    assert l2rel(params["decoder.conv_out.weight"].grad, ref_sd["decoder.conv_out.weight"].grad) < 3e-2
-    assert l2rel(params["encoder.conv_in.weight"].grad, ref_sd["encoder.conv_in.weight"].grad) < 1.5 * 0.17
+    for k in ("decoder.conv_out.weight", "encoder.conv_in.weight"):
+        assert l2rel(params[k].grad, ref_sd[k].grad) < max(3e-2, 1.5 * ref16["g:" + k]), k
     norms = []
     for k, p in params.items():
         rg = ref_sd[k].grad
@@ -214,7 +231,11 @@ def test_f8_style_config_against_oracle():
         recon, mu, logvar = m(x.to(DEV), eps=eps.to(DEV))
     r_ref, mu_ref, lv_ref = O.forward(x, sd, cfg, eps)
     assert mu.shape == (2, 4, 8, 8) and recon.shape == x.shape
-    assert l2rel(recon, r_ref) < 2.5e-2 and l2rel(mu, mu_ref) < 1.5e-2 and l2rel(logvar, lv_ref) < 2e-2
+    ref16 = _extra_ref16()["f8_micro"]
+    errs = {"recon": l2rel(recon, r_ref), "mu": l2rel(mu, mu_ref), "logvar": l2rel(logvar, lv_ref)}
+    print("f8 micro rel-L2 vs oracle:", errs, "reference bf16:", {k: ref16[k] for k in errs})
+    for k, e in errs.items():
+        assert e < max(1e-2, 1.0 * ref16[k]), (k, e, ref16[k])
 
 
 def test_micro_model_tuple_forward_uses_global_rng_and_clamp_variant():
@@ -297,7 +318,7 @@ def test_tiny_config1_against_reference_golden(golden_dir):
             ref = g[f"{nm}.{b}.val"]
             got = flat[g[f"{nm}.{b}.idx"]]
             err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
-            # 64 sampled elements per tensor: a noisy estimate of the full-tensor error, hence 2x (not 1.25x)
+            # 64 sampled elements per tensor: a noisy estimate of the full-tensor error (+-25 %), hence 2x here (full tensors: 1.0x)
             assert err < max(1e-2, 2.0 * float(g[f"{nm}.{b}.bf16_autocast_l2rel"])), (nm, b, err)
             assert abs(flat.std(ddof=1) - float(g[f"{nm}.{b}.std"])) < 2e-2 * float(g[f"{nm}.{b}.std"])
 
@@ -336,8 +357,10 @@ def test_large_f16d32_256_full_size_properties_and_oracle():
         r_ref, mu_ref, lv_ref = O.forward(x[:1], sd, cfg, eps[:1])
     errs = (l2rel(recon[:1], r_ref), l2rel(mu[:1], mu_ref), l2rel(logvar[:1], lv_ref))
     print("large f16d32 256x256 rel-L2 vs oracle (recon, mu, logvar):", errs)
-    # bf16 tier, same bounds as the micro / tiny tests (measured on MI355X: 1.4e-2 / 1.1e-2 / 1.1e-2)
-    assert errs[0] < 2.5e-2 and errs[1] < 1.5e-2 and errs[2] < 2e-2, errs
+    # bf16 tier: within the reference's own bf16-autocast deviation at this model size (2.4e-2 / 1.4e-2 / 1.6e-2 on the
+    # filler weights, tests/golden/large_ref_bf16_autocast.json; measured on MI355X: 1.4e-2 / 1.1e-2 / 1.1e-2)
+    r16 = _large_ref16()
+    assert errs[0] < max(1e-2, r16["recon"]) and errs[1] < max(1e-2, r16["mu"]) and errs[2] < max(1e-2, r16["logvar"]), errs
 
 
 def test_large_f16d32_256_gradients_add_over_images():
@@ -373,3 +396,167 @@ def test_large_f16d32_256_gradients_add_over_images():
             worst = (k, e)
     print("largest deviation of a batch gradient from the mean of its images' gradients:", worst)
     assert worst[1] < 1e-5, worst   # measured 6.7e-7 (fp32 summation order)
+
+
+# ---- full-size parity: gradients at Large, the 512x512 path (BASELINE config 4), giant sizing (config 5) ------------------
+def _large_filled():
+    from transvae import TransVAE
+    cfg = O.variant_config("large", 16, 32)
+    sd = filler.fill_state_dict(O.state_dict_schema(cfg, 32))
+    m = TransVAE(variant="large", compression_ratio=16, latent_dim=32)
+    m.load_state_dict(sd)
+    return m.to(DEV), sd, cfg
+
+
+def test_large_one_image_forward_backward_against_oracle_and_reference_golden(golden_dir):
+    """TransVAE-Large f16d32 at 256 x 256, ONE image, forward AND backward: the HIP path against the fp32 oracle on full
+    tensors (20 named gradients: stem, N = 4096 attention projections, 1536-wide 3x3 FFN convolutions, DC paths, heads),
+    and the oracle against the reference's own sampled values (tests/golden/large_one_image.npz, minted by
+    oracle/make_goldens.py --large).  Tolerance: the reference's OWN bf16-autocast deviation on the same tensors
+    (large_ref_bf16_autocast.json) -- outputs within max(1e-2, 1.0 x), gradients within max(3e-2, 1.5 x)."""
+    g = golden(golden_dir, "large_one_image.npz")
+    with open(os.path.join(golden_dir, "large_ref_bf16_autocast.json")) as f:
+        ref16 = json.load(f)
+    m, sd, cfg = _large_filled()
+    m.train()
+    x = filler.rand_input("large.x", (1, 3, 256, 256))
+    eps = filler.randn_input("large.eps", (1, 32, 16, 16))
+    recon, mu, logvar = m(x.to(DEV), eps=eps.to(DEV))
+    O.bench_loss(recon, x.to(DEV), mu, logvar).backward()
+    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    outs = {"recon": recon.detach().cpu(), "mu": mu.detach().cpu(), "logvar": logvar.detach().cpu()}
+    del m, recon, mu, logvar
+    torch.cuda.empty_cache()
+    keys = [k[2:-4] for k in g if k.startswith("g:") and k.endswith(".idx")]
+    assert len(keys) >= 10
+    ref_sd = {k: v.requires_grad_(k in keys) for k, v in sd.items()}
+    r_ref, mu_ref, lv_ref = O.forward(x, ref_sd, cfg, eps)
+    loss = O.bench_loss(r_ref, x, mu_ref, lv_ref)
+    loss.backward()
+    # (1) the oracle reproduces the reference at full size (fp32 vs fp32: 1e-4 on sampled values, 1e-5 on norms and the loss)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    for nm, t in (("recon", r_ref), ("mu", mu_ref), ("logvar", lv_ref)):
+        got = t.detach().flatten().double()[g[f"{nm}.idx"]].numpy()
+        assert np.linalg.norm(got - g[f"{nm}.val"]) < 1e-4 * np.linalg.norm(g[f"{nm}.val"]), nm
+        assert abs(float(t.double().norm()) - float(g[f"{nm}.l2"])) < 1e-5 * float(g[f"{nm}.l2"]), nm
+    for k in keys:
+        rg = ref_sd[k].grad.flatten()
+        got = rg[g[f"g:{k}.idx"]].double().numpy()
+        assert np.linalg.norm(got - g[f"g:{k}.val"]) < 2e-3 * np.linalg.norm(g[f"g:{k}.val"]) + 1e-12, k
+        assert abs(float(rg.double().norm()) - float(g[f"g:{k}.l2"])) < 1e-3 * float(g[f"g:{k}.l2"]) + 1e-12, k
+    # (2) the HIP path against the oracle, full tensors
+    errs = {nm: l2rel(outs[nm], t) for nm, t in (("recon", r_ref), ("mu", mu_ref), ("logvar", lv_ref))}
+    gerrs = {k: l2rel(grads[k], ref_sd[k].grad) for k in keys}
+    print("large outputs rel-L2 vs oracle:", {k: round(v, 4) for k, v in errs.items()},
+          " reference's own bf16 deviation:", {k: round(ref16[k], 4) for k in errs})
+    print("large gradients rel-L2 vs oracle (ours / reference's own bf16 deviation):")
+    for k in keys:
+        print(f"   {k:46s} {gerrs[k]:.4f} / {ref16['g:' + k]:.4f}")
+    for nm, e in errs.items():
+        assert e < max(1e-2, 1.0 * ref16[nm]), (nm, e, ref16[nm])
+    for k in keys:
+        assert gerrs[k] < max(3e-2, 1.5 * ref16["g:" + k]), (k, gerrs[k], ref16["g:" + k])
+
+
+def test_stage2_block_at_512px_tokens_16384_against_oracle():
+    """BASELINE config 4's new shape: the stage-2 TransVAE block of Large at a 512 x 512 input = 128 x 128 tokens
+    (N = 16 384, 6 heads) -- RoPE tables beyond the 256-pixel grid, 128 key tiles per query tile -- forward and backward
+    against the fp32 oracle block (R/transvae/modules/blocks.py:89-151; scripts/reproduce/test_rope_extrapolation.py:28-51
+    is the reference's use of this shape)."""
+    from transvae.modules.blocks import TransVAEBlock
+    blk = TransVAEBlock(dim=384)
+    sd = {k: filler.fill_tensor("b512." + k, v.shape) for k, v in blk.state_dict().items()}
+    blk.load_state_dict(sd)
+    blk = blk.to(DEV)
+    x = filler.randn_input("b512.x", (1, 384, 128, 128))
+    gy = filler.randn_input("b512.gy", (1, 384, 128, 128))
+    xd = x.to(DEV).requires_grad_(True)
+    y = blk(xd)
+    y.backward(gy.to(DEV))
+    ref_sd = {"b." + k: v.clone().requires_grad_(not k.endswith("inv_freq")) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.transvae_block(xr, ref_sd, "b.")
+    yr.backward(gy)
+    assert l2rel(y, yr) < TOL_OUT, l2rel(y, yr)
+    assert l2rel(xd.grad, xr.grad) < TOL_GRAD, l2rel(xd.grad, xr.grad)
+    worst = max((l2rel(p.grad, ref_sd["b." + k].grad), k) for k, p in blk.named_parameters())
+    print("N=16384 block: out", l2rel(y, yr), "dx", l2rel(xd.grad, xr.grad), "worst param grad", worst)
+    assert worst[0] < TOL_GRAD, worst
+
+
+def test_large_512_one_image_forward_against_oracle():
+    """BASELINE config 4's correctness leg: TransVAE-Large f16d32 on ONE 512 x 512 image (token grids 128^2 / 64^2 / 32^2,
+    10.5 TFLOP forward) against the fp32 oracle; same bf16-tier bounds as the 256 x 256 test."""
+    import bench
+    from transvae import TransVAE
+    with torch.device(DEV):
+        m = TransVAE(variant="large", compression_ratio=16, latent_dim=32)
+    bench.init_scaled_(m, seed=3)
+    m.eval()
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(1, 3, 512, 512, generator=g)
+    eps = torch.randn(1, 32, 32, 32, generator=g)
+    with torch.no_grad():
+        recon, mu, logvar = m(x.to(DEV), eps=eps.to(DEV))
+    assert recon.shape == x.shape and mu.shape == (1, 32, 32, 32) and torch.isfinite(recon).all()
+    cfg = O.variant_config("large", 16, 32)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        r_ref, mu_ref, lv_ref = O.forward(x, sd, cfg, eps)
+    errs = (l2rel(recon, r_ref), l2rel(mu, mu_ref), l2rel(logvar, lv_ref))
+    print("large f16d32 512x512 rel-L2 vs oracle (recon, mu, logvar):", errs)
+    r16 = _large_ref16()      # (the 256 x 256 yardstick: the reference's bf16 run at 512 x 512 takes minutes on the CPU)
+    assert errs[0] < max(1e-2, r16["recon"]) and errs[1] < max(1e-2, r16["mu"]) and errs[2] < max(1e-2, r16["logvar"]), errs
+
+
+def test_giant_f16d32_train_step_fits_288gb():
+    """BASELINE config 5 ("XL" = giant f16d32, 4.84 B parameters as coded): one full train step (micro-batch 8)
+    on one GPU; peak device memory must stay below the 288 GB of an MI355X and the parameter / gradient / optimizer /
+    operand / activation split is written to gpurun_out/giant_sizing.json (tracked copy: profiles/r02_giant_sizing.json)."""
+    from transvae import TransVAE
+    from transvae.optim import FusedAdamW
+    from transvae.parallel import train_step, vae_bench_loss
+    import bench
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.device(DEV):
+        m = TransVAE(variant="giant", compression_ratio=16, latent_dim=32, clamp_latent=True)
+    bench.init_scaled_(m, seed=0)
+    m.train()
+    n_params = m.get_num_params()["total"]
+    assert n_params == 4836751747 or n_params > 4.8e9, n_params
+    after_params = torch.cuda.memory_allocated()
+    opt = FusedAdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0)
+    after_opt = torch.cuda.memory_allocated()
+    mb = 8
+    x = torch.rand(mb, 3, 256, 256, device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+
+    def forward_loss(model, xb):
+        eps = torch.randn(xb.shape[0], 32, 16, 16, device=DEV, generator=gen)
+        recon, mu, logvar = model(xb, eps=eps)
+        return vae_bench_loss(recon, xb, mu, logvar)
+    counters = {}
+    loss = train_step(m, opt, x, mb, forward_loss, 1.0, mb, counters)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated()
+    after_step = torch.cuda.memory_allocated()
+    assert torch.isfinite(loss) and float(counters["skipped"]) == 0
+    gib = 2.0 ** 30
+    rep = {"variant": "giant_f16d32", "params": n_params, "micro_batch": mb, "resolution": 256,
+           "param_fp32_gib": round((after_params - base) / gib, 2),
+           "bf16_operand_copies_gib": round((after_opt - after_params) / gib, 2),
+           "grads_plus_adam_moments_plus_transposed_operands_gib": round((after_step - after_opt) / gib, 2),
+           "peak_gib": round(peak / gib, 2),
+           "activations_and_workspace_at_peak_gib": round((peak - after_step) / gib, 2),
+           "activation_gib_per_image": round((peak - after_step) / gib / mb, 3),
+           "hbm_gib": 288, "loss": float(loss)}
+    rep["largest_micro_batch_that_fits"] = int((288 * 1e9 / gib - after_step / gib) / max(rep["activation_gib_per_image"], 1e-6))
+    print("giant sizing:", rep)
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "giant_sizing.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    assert peak < 288e9, rep
+    del m, opt
+    torch.cuda.empty_cache()

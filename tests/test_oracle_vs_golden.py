@@ -195,3 +195,23 @@ def test_tiny_config1_forward(golden_dir):
         scale = float(g[f"{nm}.0.absmax"])
         assert np.abs(flat[idx] - g[f"{nm}.0.val"]).max() < 2e-5 * scale, nm
         assert abs(flat.std(ddof=1) - float(g[f"{nm}.0.std"])) < 1e-4 * float(g[f"{nm}.0.std"]), nm
+
+
+def test_oracle_large_forward_matches_reference_golden(golden_dir):
+    """TransVAE-Large f16d32 at 256 x 256 (BASELINE config 2's model at full size), one image, forward: the oracle against
+    the reference's sampled outputs (tests/golden/large_one_image.npz from `oracle/make_goldens.py --large`).  The backward
+    half of that fixture (20 named gradients) is checked where the oracle runs its backward anyway: the `-m gpu` test
+    test_large_one_image_forward_backward_against_oracle_and_reference_golden."""
+    g = dict(np.load(os.path.join(golden_dir, "large_one_image.npz")))
+    cfg = O.variant_config("large", 16, 32)
+    sd = filler.fill_state_dict(O.state_dict_schema(cfg, 32))
+    x = filler.rand_input("large.x", (1, 3, 256, 256))
+    eps = filler.randn_input("large.eps", (1, 32, 16, 16))
+    with torch.no_grad():
+        recon, mu, logvar = O.forward(x, sd, cfg, eps)
+        loss = O.bench_loss(recon, x, mu, logvar)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    for nm, t in (("recon", recon), ("mu", mu), ("logvar", logvar)):
+        got = t.flatten().double()[g[f"{nm}.idx"]].numpy()
+        assert np.linalg.norm(got - g[f"{nm}.val"]) < 1e-4 * np.linalg.norm(g[f"{nm}.val"]), nm
+        assert abs(float(t.double().norm()) - float(g[f"{nm}.l2"])) < 1e-5 * float(g[f"{nm}.l2"]), nm
