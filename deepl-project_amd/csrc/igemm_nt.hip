@@ -76,6 +76,9 @@ struct IgemmArgs {
 #ifndef TV_SETPRIO
 #define TV_SETPRIO 1           // waves 4-7 (the arbitration losers on every SIMD) run at priority 1
 #endif
+#ifndef TV_HALO_PP
+#define TV_HALO_PP 0       // wave-group ping-pong main loop of the 8-wave halo tiles (see conv3x3_halo_kernel)
+#endif
 #ifndef TV_NO_PINGPONG
 #define TV_NO_PINGPONG 1   // ping-pong main loop of the 8-wave tiles: measured, not (yet) a win -- see DESIGN.md
 #endif
@@ -960,7 +963,87 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
     };
 
     // ---- main loop ------------------------------------------------------------------------------------------------------
-    if constexpr (PIPE_ALL && !TV_NO_PIPE2) {
+    // Wave-group ping-pong (8-wave tiles, 3-deep weight ring).  Waves w and w+4 share a SIMD.  In the lockstep loops below
+    // both of them read fragments, issue DMAs and multiply at the same moments, so nothing covers the non-matrix work
+    // (ablation: DMA issue 0.5 ms + fragment reads 0.25 ms of a 2.5 ms launch are fully exposed).  Here the block runs in
+    // PHASES (one block barrier each); group 0 (waves 0-3) reads the fragments of step t and issues its DMAs in phase 2t and
+    // multiplies in phase 2t+1, group 1 (waves 4-7) does the same one phase later -- every SIMD always has one wave in its
+    // MFMA phase (at priority 1) and the other in its load phase.
+    //   phase 2t   : g0 reads step t,  issues its share of slab t+2 (+ a halo piece of the next chunk) | g1 multiplies step t-1
+    //   phase 2t+1 : g0 multiplies step t                                                              | g1 reads step t, issues its share
+    // Weight slot (t+2) % 3 held slab t-1: last read by g0 in phase 2t-2 and by g1 in phase 2t-1, so it is free in both load
+    // phases of step t.  A wave waits (counted vmcnt) at the END of each load phase for everything it issued in EARLIER load
+    // phases: slab t+2 has landed and is visible (next barrier) one full step before g0 reads it.  The halo pieces of chunk
+    // c+1 go out during taps 0-5 of chunk c into the buffer last read at the final tap of chunk c-1.
+    constexpr bool PP = TV_HALO_PP && NW == 8 && PIPE_ALL && BST == 3;
+    if constexpr (PP) {
+        static_assert(NWL == NW, "ping-pong: every wave loads");
+        constexpr int ATAPS = 6, A_PT = (A_IT + ATAPS - 1) / ATAPS;
+        static_assert(A_PT == 1, "one halo piece per wave and tap");
+        constexpr auto nsure = [](int tap) { return (tap >= 0 && tap < ATAPS && tap < A_IT && (tap + 1) * NW <= A_PIECES) ? 1 : 0; };
+        const int grp = wave >> 2;
+        bf16x8 fa[2][MF], fb[2][NF];
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) issue_a(a_buf, it, 0);
+        issue_b(b_buf, 0, 0);
+        issue_b(b_buf + B_BYTES, 1, 0);
+        wait_vmcnt<0>();
+        if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one phase behind
+        int bcur = 0;
+        for (int ch = 0; ch < cch; ++ch) {
+            const char* acur = a_buf + (ch & 1) * A_BYTES;
+            char* anxt = a_buf + ((ch + 1) & 1) * A_BYTES;
+            const bool more = ch + 1 < cch;
+            static_for<0, 9>([&](auto tap_c) {
+                constexpr int tap = decltype(tap_c)::value;
+                constexpr int toff = (tap / 3) * HWD + (tap % 3);
+                const char* const bslot = b_buf + bcur * B_BYTES;
+                char* const bfill = b_buf + ((bcur + 2 >= BST) ? bcur + 2 - BST : bcur + 2) * B_BYTES;
+                // ---- load phase --------------------------------------------------------------------------------------------
+                __builtin_amdgcn_s_barrier();
+                int hpb = hp_base;
+                asm volatile("" : "+v"(hpb));   // pin the address arithmetic to this tap
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < MF; ++i) {
+                        const int hp = hpb + i * HWD + toff;
+                        fa[kk][i] = *(const bf16x8*)(acur + hp * (BK * 2) + (((kk * 4 + fq) ^ (hp & 7)) << 4));
+                    }
+                    const int coff = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) fb[kk][j] = *(const bf16x8*)(bslot + b_row_off + j * 4 * (BK * 2) + coff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bool b_go = (tap + 2 < 9) || more;
+                if (tap < ATAPS && tap < A_IT && more) issue_a(anxt, tap, ch + 1);
+                if (b_go) {
+                    const int b_koff = ((tap + 2 < 9) ? (tap + 2) * p.c_in + ch * BK : (tap + 2 - 9) * p.c_in + (ch + 1) * BK) * 2;
+#pragma unroll
+                    for (int it = 0; it < B_IT; ++it) issue_b_piece(bfill, it, b_koff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers: the slot may be refilled two barriers on
+                if (more) wait_vmcnt<B_IT + nsure(tap)>();          // everything issued in EARLIER load phases has landed
+                else if (tap + 2 < 9) wait_vmcnt<B_IT>();
+                else wait_vmcnt<0>();
+                // ---- MFMA phase --------------------------------------------------------------------------------------------
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < MF; ++i)
+#pragma unroll
+                        for (int j = 0; j < NF; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                bcur = (bcur + 1 == BST) ? 0 : bcur + 1;
+            });
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();   // (both groups have passed the same number of barriers)
+    } else if constexpr (PIPE_ALL && !TV_NO_PIPE2) {
         // Register-pipelined like the generic kernel: two half-step (32-deep) fragment sets per wave; the block barrier sits
         // between the halves of a step, when every wave has read all of step t.  After it the weight slot of step t is
         // refilled with step t+BST and the halo pieces of the next chunk go out (taps 0-5), threaded between the MFMAs of
