@@ -108,6 +108,9 @@ __device__ __forceinline__ void gn_prepare(const float* stats_b, const bf16* x_b
     __syncthreads();
 }
 
+// FROM_MR: the statistics are READ from mr (the mean / rstd a forward call wrote) instead of being derived from the channel
+// sums -- the recompute of silu(gn(x)) in the backward pass of a checkpointed ResBlock: same scale / shift bits, same output.
+template <bool FROM_MR>
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ stats,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float* __restrict__ mr, bf16* __restrict__ y, int hw, int C, int G,
@@ -118,12 +121,23 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const bf16* __r
     float* s_mean = s_shift + C;
     float* s_rstd = s_mean + G;
     const int b = blockIdx.y;
-    gn_prepare(stats + (size_t)b * C * 2, x + (size_t)b * hw * C, gamma, beta, s_scale, s_shift, s_mean, s_rstd, hw, C, G, eps);
-    if (blockIdx.x == 0)
-        for (int g = threadIdx.x; g < G; g += GN_THREADS) {
-            mr[((size_t)b * G + g) * 2] = s_mean[g];
-            mr[((size_t)b * G + g) * 2 + 1] = s_rstd[g];
+    if constexpr (FROM_MR) {
+        const int cpg = C / G;
+        for (int c = threadIdx.x; c < C; c += GN_THREADS) {
+            const int g = c / cpg;
+            const float sc = mr[((size_t)b * G + g) * 2 + 1] * gamma[c];
+            s_scale[c] = sc;
+            s_shift[c] = beta[c] - mr[((size_t)b * G + g) * 2] * sc;
         }
+        __syncthreads();
+    } else {
+        gn_prepare(stats + (size_t)b * C * 2, x + (size_t)b * hw * C, gamma, beta, s_scale, s_shift, s_mean, s_rstd, hw, C, G, eps);
+        if (blockIdx.x == 0)
+            for (int g = threadIdx.x; g < G; g += GN_THREADS) {
+                mr[((size_t)b * G + g) * 2] = s_mean[g];
+                mr[((size_t)b * G + g) * 2 + 1] = s_rstd[g];
+            }
+    }
     // one 16-byte channel chunk per thread for the whole slab: scale / shift in registers
     const int nch = C >> 3;
     const int rows = GN_THREADS / nch;
@@ -528,9 +542,20 @@ extern "C" int tv_gn_silu_fwd(const void* x, const float* stats, const float* ga
     if (gn_check("tv_gn_silu_fwd", batch, hw, C, G)) return TV_ERR_ARG;
     TV_CHECK_ARG(x && stats && gamma && beta && mr && y, "tv_gn_silu_fwd: null pointer");
     dim3 grid(tv_cdiv(hw, GN_PIX_PER_BLOCK), batch);
-    hipLaunchKernelGGL(gn_silu_fwd_kernel, grid, dim3(GN_THREADS), (2 * C + 2 * G) * sizeof(float), (hipStream_t)stream, (const bf16*)x,
+    hipLaunchKernelGGL(gn_silu_fwd_kernel<false>, grid, dim3(GN_THREADS), (2 * C + 2 * G) * sizeof(float), (hipStream_t)stream, (const bf16*)x,
                        stats, gamma, beta, mr, (bf16*)y, hw, C, G, eps);
     TV_CHECK_LAUNCH("tv_gn_silu_fwd");
+    return TV_OK;
+}
+
+extern "C" int tv_gn_silu_apply(const void* x, const float* mr, const float* gamma, const float* beta, void* y, int batch, int hw,
+                                int C, int G, void* stream) {
+    if (gn_check("tv_gn_silu_apply", batch, hw, C, G)) return TV_ERR_ARG;
+    TV_CHECK_ARG(x && mr && gamma && beta && y, "tv_gn_silu_apply: null pointer");
+    dim3 grid(tv_cdiv(hw, GN_PIX_PER_BLOCK), batch);
+    hipLaunchKernelGGL(gn_silu_fwd_kernel<true>, grid, dim3(GN_THREADS), (2 * C + 2 * G) * sizeof(float), (hipStream_t)stream, (const bf16*)x,
+                       nullptr, gamma, beta, const_cast<float*>(mr), (bf16*)y, hw, C, G, 0.f);
+    TV_CHECK_LAUNCH("tv_gn_silu_apply");
     return TV_OK;
 }
 

@@ -46,6 +46,7 @@ SIGNATURES = {
     "tv_gn_partial_count": (_LL, [_I, _I, _I]),
     "tv_gn_stats": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "tv_gn_silu_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "tv_gn_silu_apply": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tv_gn_silu_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tv_gn_silu_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "tv_rownorm_fwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _P]),

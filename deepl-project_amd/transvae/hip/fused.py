@@ -51,6 +51,14 @@ def gn_silu_fwd(x, gamma, beta, groups, eps):
     return y, mr
 
 
+def gn_silu_apply(x, mr, gamma, beta, groups):
+    """silu(groupnorm(x)) recomputed from saved mean / rstd (bit-identical to gn_silu_fwd's output)."""
+    B, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    L.check(L.load().tv_gn_silu_apply(_p(x), _p(mr), _p(gamma), _p(beta), _p(y), B, H * W, Cc, groups, _stream()), "tv_gn_silu_apply")
+    return y
+
+
 def gn_silu_bwd(x, dy, dres, mr, gamma, beta, groups):
     """(dx [+ dres], dgamma, dbeta)"""
     B, H, W, Cc = x.shape
@@ -132,8 +140,13 @@ def _join(ctx, device):
 # ResBlock (identity shortcut)   R/transvae/modules/blocks.py:48-68
 # ------------------------------------------------------------------------------------------------
 class ResBlockFn(torch.autograd.Function):
+    """recompute = the activation-checkpointing toggle (R/transvae/models/encoder.py:97-99,117-118) as a FUSED-OP recompute:
+    the two GroupNorm+SiLU outputs (the operands of the two weight gradients) are not saved; the backward rebuilds each from
+    the tensor it normalised and the saved mean / rstd (one HBM pass each, bit-identical), so a block keeps 2 full-resolution
+    tensors instead of 4 and no convolution runs twice."""
+
     @staticmethod
-    def forward(ctx, x, g1, b1, w1, c1b, g2, b2, w2, c2b, eps1, eps2):
+    def forward(ctx, x, g1, b1, w1, c1b, g2, b2, w2, c2b, eps1, eps2, recompute=False):
         ops._need_gpu(x)
         g1, b1, g2, b2 = _c(g1), _c(b1), _c(g2), _c(b2)
         a1, mr1 = gn_silu_fwd(x, g1, b1, 32, eps1)
@@ -141,23 +154,37 @@ class ResBlockFn(torch.autograd.Function):
         a2, mr2 = gn_silu_fwd(h1, g2, b2, 32, eps2)
         out, _, geo2, w2c = conv_forward(a2, w2, c2b, x, "c3s1", NONE, False)
         ctx.geo = (geo1, geo2)
-        ctx.save_for_backward(x, a1, h1, a2, mr1, mr2, g1, b1, g2, b2, w1c, w2c)
+        ctx.recompute = bool(recompute)
+        if recompute:
+            ctx.save_for_backward(x, h1, mr1, mr2, g1, b1, g2, b2, w1c, w2c)
+        else:
+            ctx.save_for_backward(x, a1, h1, a2, mr1, mr2, g1, b1, g2, b2, w1c, w2c)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, a1, h1, a2, mr1, mr2, g1, b1, g2, b2, w1, w2 = ctx.saved_tensors
+        if ctx.recompute:
+            x, h1, mr1, mr2, g1, b1, g2, b2, w1, w2 = ctx.saved_tensors
+            a1 = a2 = None
+        else:
+            x, a1, h1, a2, mr1, mr2, g1, b1, g2, b2, w1, w2 = ctx.saved_tensors
         geo1, geo2 = ctx.geo
         g = g.contiguous()
-        da2 = conv_dgrad(geo2, w2, g, a2.shape)
+        da2 = conv_dgrad(geo2, w2, g, h1.shape)
+        if a2 is None and (ctx.needs_input_grad[7] or ctx.needs_input_grad[8]):
+            a2 = gn_silu_apply(h1, mr2, g2, b2, 32)
         dw2, dc2b = _wg(ctx, 7, 8, geo2, w2, a2, g)
+        del a2
         dh1, dg2, db2 = gn_silu_bwd(h1, da2, None, mr2, g2, b2, 32)
         del da2
-        da1 = conv_dgrad(geo1, w1, dh1, a1.shape)
+        da1 = conv_dgrad(geo1, w1, dh1, x.shape)
+        if a1 is None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
+            a1 = gn_silu_apply(x, mr1, g1, b1, 32)
         dw1, dc1b = _wg(ctx, 3, 4, geo1, w1, a1, dh1)
+        del a1
         dx, dg1, db1 = gn_silu_bwd(x, da1, g, mr1, g1, b1, 32)    # + skip-connection gradient, fused
         _join(ctx, x.device)
-        return dx, dg1, db1, dw1, dc1b, dg2, db2, dw2, dc2b, None, None
+        return dx, dg1, db1, dw1, dc1b, dg2, db2, dw2, dc2b, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -17,7 +17,7 @@ import torch.utils.checkpoint
 from ..hip import ops
 from ..modules.blocks import ResBlock, TransVAEBlock
 from ..modules.upsample import Upsample
-from .encoder import _tap
+from .encoder import _checkpointed, _tap
 
 
 def _round32(n: int) -> int:
@@ -64,7 +64,7 @@ class TransVAEDecoder(nn.Module):
         for i, stage in enumerate(self.stages):
             for j, block in enumerate(stage):
                 if self.gradient_checkpointing and self.training:
-                    h = torch.utils.checkpoint.checkpoint(block.forward_nhwc, h, use_reentrant=False)
+                    h = _checkpointed(block, h)
                 else:
                     h = block.forward_nhwc(h)
                 h = _tap(taps, f"decoder.stages.{i}.{j}", h)

@@ -27,6 +27,16 @@ def _tap(taps, key, h):
     return h
 
 
+def _checkpointed(block, h):
+    """The activation-checkpointing toggle (R/transvae/models/encoder.py:97-99,117-118; decoder.py:98-100,118-119).
+    ResBlocks (the stages that hold the large tensors) recompute only their two GroupNorm+SiLU outputs in the backward pass
+    (fused-op recompute: no convolution runs twice, 2 saved full-resolution tensors per block instead of 4); TransVAE
+    blocks are re-run as a whole like the reference does."""
+    if getattr(block, "supports_fused_recompute", False) and isinstance(block.shortcut, nn.Identity):
+        return block.forward_nhwc(h, recompute=True)
+    return torch.utils.checkpoint.checkpoint(block.forward_nhwc, h, use_reentrant=False)
+
+
 class TransVAEEncoder(nn.Module):
     NUM_CNN_STAGES = 2  # hard-coded in the reference (encoder.py:60)
 
@@ -75,7 +85,7 @@ class TransVAEEncoder(nn.Module):
         for i, stage in enumerate(self.stages):
             for j, block in enumerate(stage):
                 if self.gradient_checkpointing and self.training:
-                    h = torch.utils.checkpoint.checkpoint(block.forward_nhwc, h, use_reentrant=False)
+                    h = _checkpointed(block, h)
                 else:
                     h = block.forward_nhwc(h)
                 h = _tap(taps, f"encoder.stages.{i}.{j}", h)

@@ -47,11 +47,14 @@ class ResBlock(nn.Module):
         else:
             self.shortcut = nn.Identity()
 
-    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+    # fused-op recompute available (the checkpointing toggle of the encoder / decoder uses it instead of re-running the block)
+    supports_fused_recompute = True
+
+    def forward_nhwc(self, x: torch.Tensor, recompute: bool = False) -> torch.Tensor:
         if isinstance(self.shortcut, nn.Identity):   # every shipped config: one fused forward/backward
             return fused.ResBlockFn.apply(x, self.norm1.weight, self.norm1.bias, krsc(self.conv1), self.conv1.bias,
                                           self.norm2.weight, self.norm2.bias, krsc(self.conv2), self.conv2.bias,
-                                          self.norm1.eps, self.norm2.eps)
+                                          self.norm1.eps, self.norm2.eps, recompute)
         a = ops.group_norm_silu(x, self.norm1.weight, self.norm1.bias, 32, self.norm1.eps)
         h = ops.conv(a, krsc(self.conv1), self.conv1.bias, None, "c3s1")
         a = ops.group_norm_silu(h, self.norm2.weight, self.norm2.bias, 32, self.norm2.eps)

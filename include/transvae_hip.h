@@ -134,6 +134,10 @@ int tv_gn_stats(const void* x, float* stats, float* partials, int batch, int hw,
 /* y = silu(groupnorm(x)); stats from tv_gn_stats; writes mean/rstd per (b,group) to mr[b][G][2] */
 int tv_gn_silu_fwd(const void* x, const float* stats, const float* gamma, const float* beta,
                    float* mr, void* y, int batch, int hw, int C, int G, float eps, void* stream);
+/* y = silu(groupnorm(x)) again from the mean / rstd a tv_gn_silu_fwd call wrote to mr: the fused-op recompute of a
+ * checkpointed ResBlock (R/transvae/models/encoder.py:97-99,117-118: activation checkpointing) -- bit-identical to the forward */
+int tv_gn_silu_apply(const void* x, const float* mr, const float* gamma, const float* beta, void* y,
+                     int batch, int hw, int C, int G, void* stream);
 /* backward pass 1: red[b][c][0] = sum dh, red[b][c][1] = sum dh*xhat   (dh = dy * silu'(h)) */
 int tv_gn_silu_bwd_reduce(const void* x, const void* dy, const float* mr, const float* gamma,
                           const float* beta, float* red, float* partials, int batch, int hw, int C,
