@@ -60,6 +60,8 @@ SIGNATURES = {
     "tv_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "tv_im2col3x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "tv_pool2x2_sum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "tv_vae_loss_partial_count": (_LL, [_LL, _LL]),
+    "tv_vae_loss_l1_kl": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _LL, _F, _F, _F, _I, _F, _F, _P]),
     "tv_opt_chunk_elems": (_I, []),
     "tv_opt_grad_norm": (_I, [_P, _P, _I, _P, _P, _F, _F, _F, _I, _P]),
     "tv_opt_adamw": (_I, [_P, _P, _I, _P, _F, _F, _F, _F, _F, _P]),

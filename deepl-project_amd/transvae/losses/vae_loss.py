@@ -1,0 +1,90 @@
+"""Closed-form terms of the reference loss on the path's outputs, one HIP pass for value and gradient.
+
+Interface mirror of R/transvae/losses/vae_loss.py (`TransVAELoss(l1_weight, lpips_weight, kl_weight, vf_weight, gan_weight,
+use_gan)`, `forward(reconstruction, target, mu, logvar, discriminator=None, dinov2=None) -> dict` with keys 'l1', 'kl', 'total').
+What is NOT here, and why: LPIPS (an external VGG network fetched over the network), VF (DINOv2) and the GAN term (a
+discriminator network) consume the path's outputs but are other networks -- out of scope; asking for them
+raises.  The two closed-form terms are
+
+    l1 = l1_weight * mean |reconstruction - target|                                   (vae_loss.py:83-84)
+    kl = kl_weight * -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) / (B * H_lat * W_lat)  (vae_loss.py:94-96)
+
+with the patched copy's variants as options: `sigmoid_recon=True` (P/.../vae_loss.py:80-84), `kl_mean=True` and
+`logvar_clip=(-30, 20)` (P/.../vae_loss.py:96-102; the bf16 trainer clamps before calling the loss, R/train_2.py:316-318).
+`tv_vae_loss_l1_kl` reads each tensor once and writes the three gradients in the same pass.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ..hip import _lib as L
+from ..hip import ops
+
+
+class _FusedL1KL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, recon, target, mu, logvar, l1_weight, kl_weight, kl_mean, sigmoid, lo, hi):
+        ops._need_gpu(recon, target, mu, logvar)
+        recon_c, mu_c, lv_c = recon.float().contiguous(), mu.float().contiguous(), logvar.float().contiguous()
+        # the pair (recon, target) is walked flat: both must share one layout
+        target_c = target.float().contiguous()
+        ops._require(recon_c.shape == target_c.shape and mu_c.shape == lv_c.shape and mu_c.dim() == 4,
+                     "loss: reconstruction / target and mu / logvar must have equal shapes ([B, D, H, W] latents)")
+        lib = L.load()
+        n_img, n_lat = recon_c.numel(), mu_c.numel()
+        denom = float(n_lat) if kl_mean else float(mu_c.shape[0] * mu_c.shape[2] * mu_c.shape[3])
+        need = ctx.needs_input_grad
+        d_recon = torch.empty_like(recon_c) if need[0] else None
+        d_mu = torch.empty_like(mu_c) if need[2] else None
+        d_lv = torch.empty_like(lv_c) if need[3] else None
+        part = torch.empty((lib.tv_vae_loss_partial_count(n_img, n_lat),), dtype=torch.float32, device=recon.device)
+        out = torch.empty((3,), dtype=torch.float32, device=recon.device)
+        with torch.cuda.device(recon.device):
+            L.check(lib.tv_vae_loss_l1_kl(ops._p(recon_c), ops._p(target_c), ops._p(mu_c), ops._p(lv_c), ops._p(d_recon), ops._p(d_mu),
+                                          ops._p(d_lv), ops._p(part), ops._p(out), n_img, n_lat, float(l1_weight), float(kl_weight), denom,
+                                          int(bool(sigmoid)), float(lo), float(hi), ops._stream()), "tv_vae_loss_l1_kl")
+        ctx.save_for_backward(d_recon, d_mu, d_lv)
+        ctx.dtypes = (recon.dtype, mu.dtype, logvar.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d_recon, d_mu, d_lv = ctx.saved_tensors
+        # out = (l1, kl, total): the stored gradients are those of `total`; l1 depends on recon only, kl on mu / logvar only
+        g_r = g[0] + g[2]
+        g_k = g[1] + g[2]
+        dr = (d_recon * g_r).to(ctx.dtypes[0]) if d_recon is not None else None
+        dm = (d_mu * g_k).to(ctx.dtypes[1]) if d_mu is not None else None
+        dl = (d_lv * g_k).to(ctx.dtypes[2]) if d_lv is not None else None
+        return dr, None, dm, dl, None, None, None, None, None, None
+
+
+def fused_l1_kl(reconstruction: torch.Tensor, target: torch.Tensor, mu: torch.Tensor, logvar: torch.Tensor,
+                l1_weight: float = 1.0, kl_weight: float = 1e-8, kl_mean: bool = False, sigmoid_recon: bool = False,
+                logvar_clip: Optional[Tuple[float, float]] = None) -> torch.Tensor:
+    """[l1, kl, total] (weighted) as one fp32 tensor of 3 elements; differentiable w.r.t. reconstruction, mu, logvar."""
+    lo, hi = logvar_clip if logvar_clip is not None else (0.0, 0.0)
+    return _FusedL1KL.apply(reconstruction, target, mu, logvar, l1_weight, kl_weight, kl_mean, sigmoid_recon, lo, hi)
+
+
+class TransVAELoss(nn.Module):
+    def __init__(self, l1_weight: float = 1.0, lpips_weight: float = 0.0, kl_weight: float = 1e-8, vf_weight: float = 0.0,
+                 gan_weight: float = 0.0, use_gan: bool = False, sigmoid_recon: bool = False, kl_mean: bool = False,
+                 logvar_clip: Optional[Tuple[float, float]] = None):
+        super().__init__()
+        if lpips_weight != 0.0 or vf_weight != 0.0 or use_gan:
+            raise ValueError("TransVAELoss (HIP path): LPIPS / VF / GAN terms need external networks (VGG, DINOv2, a discriminator) "
+                             "and are outside this build; construct with lpips_weight=0, vf_weight=0, use_gan=False and add "
+                             "those terms with the reference's own modules")
+        self.l1_weight, self.lpips_weight, self.kl_weight = l1_weight, lpips_weight, kl_weight
+        self.vf_weight, self.gan_weight, self.use_gan = vf_weight, gan_weight, use_gan
+        self.sigmoid_recon, self.kl_mean, self.logvar_clip = sigmoid_recon, kl_mean, logvar_clip
+
+    def forward(self, reconstruction, target, mu, logvar, discriminator=None, dinov2=None) -> dict:
+        out = fused_l1_kl(reconstruction, target, mu, logvar, self.l1_weight, self.kl_weight, self.kl_mean, self.sigmoid_recon,
+                          self.logvar_clip)
+        return {"l1": out[0], "kl": out[1], "total": out[2]}

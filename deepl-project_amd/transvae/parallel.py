@@ -47,6 +47,9 @@ def vae_bench_loss(recon: torch.Tensor, x: torch.Tensor, mu: torch.Tensor, logva
     R/transvae/losses/vae_loss.py:83-84 (L1 = mean |recon - target|) and :94-96 (KL summed over everything and divided
     by batch * H_lat * W_lat, i.e. summed over the latent channels and averaged over batch and latent pixels).  logvar is
     clamped to [-30, 20] first, as the bf16 trainer does before it calls the loss (R/train_2.py:316-318)."""
+    if recon.is_cuda:      # one HIP pass: value and the three gradients (SURVEY 8f-2)
+        from .losses.vae_loss import fused_l1_kl
+        return fused_l1_kl(recon, x, mu, logvar, 1.0, kl_weight, logvar_clip=(-30.0, 20.0))[2]
     l1 = (recon.float() - x.float()).abs().mean()
     mu32 = mu.float()
     lv = logvar.float().clamp(-30.0, 20.0)

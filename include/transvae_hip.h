@@ -223,6 +223,19 @@ typedef struct tv_pack_form {
 } tv_pack_form;
 int tv_pack_weight_multi(const tv_pack_form* forms_dev, int n_forms, long long total_tiles, void* stream);
 
+/* Closed-form loss terms on the path's outputs, value and gradient in one pass ---------------------
+ *   out[0] = l1_weight * mean |f(recon) - target|     f = identity (R/transvae/losses/vae_loss.py:83-84) or sigmoid (P/...:80-84)
+ *   out[1] = kl_weight * -0.5 * sum(1 + lv - mu^2 - exp(lv)) / kl_denom     (R/...:94-96: kl_denom = B*H_lat*W_lat;
+ *            P/...:96-102: kl_denom = numel), lv = clamp(logvar, lo, hi) when lo < hi (R/train_2.py:316-318)
+ *   out[2] = out[0] + out[1]
+ * d_recon / d_mu / d_logvar (each may be NULL) receive the gradient of out[2]; all tensors fp32, any layout shared by the
+ * tensors of a pair (they are walked flat).  partials: tv_vae_loss_partial_count(n_img, n_lat) floats of scratch. */
+long long tv_vae_loss_partial_count(long long n_img, long long n_lat);
+int tv_vae_loss_l1_kl(const float* recon, const float* target, const float* mu, const float* logvar,
+                      float* d_recon, float* d_mu, float* d_logvar, float* partials, float* out,
+                      long long n_img, long long n_lat, float l1_weight, float kl_weight, float kl_denom,
+                      int sigmoid, float logvar_lo, float logvar_hi, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -372,3 +372,41 @@ def test_fused_adamw_keeps_the_bf16_operands_current():
     d, t = ops.pack_weight(views()[0], True, True, True)
     rd, rt = fresh(views()[0].detach(), True)
     assert torch.equal(d, rd) and torch.equal(t, rt) and d.data_ptr() != opt._shadow[id(w)].data_ptr()
+
+
+# ---- the closed-form loss in one HIP pass --------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["reference", "patched"])
+def test_fused_l1_kl_loss_matches_the_reference_formulas(variant):
+    """R/transvae/losses/vae_loss.py:83-84,94-96 (variant 'reference') and P/.../vae_loss.py:80-84,96-102 ('patched': sigmoid
+    on the reconstruction, mean-KL, logvar clamp) written out with torch ops on the CPU in float64, against
+    transvae.TransVAELoss: values to 1e-6 relative, the three gradients to 1e-5 (fp32 elementwise)."""
+    from transvae import TransVAELoss
+    g = torch.Generator().manual_seed(3)
+    recon = (torch.randn(3, 3, 40, 24, generator=g) * 0.7 + 0.4)
+    target = torch.rand(3, 3, 40, 24, generator=g)
+    mu = torch.randn(3, 8, 5, 3, generator=g) * 2
+    logvar = torch.randn(3, 8, 5, 3, generator=g) * 12          # some values outside [-30, 20]
+    patched = variant == "patched"
+    r64, m64, l64 = (t.double().requires_grad_(True) for t in (recon, mu, logvar))
+    if patched:
+        l1 = torch.nn.functional.l1_loss(r64.sigmoid(), target.double())
+        lv = l64.clamp(-30.0, 20.0)
+        kl = (-0.5 * (1.0 + lv - m64.pow(2) - lv.exp())).mean()
+    else:
+        l1 = torch.nn.functional.l1_loss(r64, target.double())
+        lv = l64.clamp(-30.0, 20.0)       # (train_2.py:316-318 clamps before the call; exp(240) is not a number worth comparing)
+        kl = -0.5 * torch.sum(1 + lv - m64.pow(2) - lv.exp()) / (mu.shape[0] * mu.shape[2] * mu.shape[3])
+    total = 1.0 * l1 + 1e-3 * kl
+    total.backward()
+    loss_fn = TransVAELoss(l1_weight=1.0, kl_weight=1e-3, sigmoid_recon=patched, kl_mean=patched, logvar_clip=(-30.0, 20.0))
+    rd, md, ld = (t.to(DEV).requires_grad_(True) for t in (recon, mu, logvar))
+    out = loss_fn(rd, target.to(DEV), md, ld)
+    assert set(out) == {"l1", "kl", "total"}
+    assert abs(float(out["l1"]) - float(l1)) < 1e-6 * float(l1)
+    assert abs(float(out["kl"]) - 1e-3 * float(kl)) < 1e-5 * abs(1e-3 * float(kl))
+    assert abs(float(out["total"]) - float(total)) < 1e-5 * abs(float(total))
+    out["total"].backward()
+    for got, ref in ((rd.grad, r64.grad), (md.grad, m64.grad), (ld.grad, l64.grad)):
+        assert float((got.cpu().double() - ref).norm()) < 1e-5 * float(ref.norm()) + 1e-12
+    with pytest.raises(ValueError, match="external networks"):
+        TransVAELoss(lpips_weight=1.0)
