@@ -257,8 +257,9 @@ def main():
     dt = float(dt)
     # every step's loss (all ranks' shares summed) and the number of skipped steps
     lt = torch.stack([l.float() for l in losses])
-    if world > 1:
+    if world > 1:      # train_step weights a rank's loss by world_size (DDP averages gradients): the mean over ranks is the loss
         dist.all_reduce(lt)
+        lt /= world
     lt = lt.cpu()
     skipped = float(counters.get("skipped", torch.zeros(()))) if counters else 0.0
     final_loss = float(lt[-1])

@@ -79,6 +79,12 @@ struct IgemmArgs {
 #ifndef TV_HALO_PP
 #define TV_HALO_PP 0       // wave-group ping-pong main loop of the 8-wave halo tiles (see conv3x3_halo_kernel)
 #endif
+#ifndef TV_PP_NM
+#define TV_PP_NM 0         // ping-pong: weight-slab DMA pieces (of B_IT per wave and step) issued from the MFMA phase
+#endif
+#ifndef TV_PP_DMA_FIRST
+#define TV_PP_DMA_FIRST 0  // ping-pong: DMA pieces of a load phase before (1) or after (0) its fragment reads
+#endif
 #ifndef TV_NO_PINGPONG
 #define TV_NO_PINGPONG 1   // ping-pong main loop of the 8-wave tiles: measured, not (yet) a win -- see DESIGN.md
 #endif
@@ -1000,7 +1006,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                 const char* const bslot = b_buf + bcur * B_BYTES;
                 char* const bfill = b_buf + ((bcur + 2 >= BST) ? bcur + 2 - BST : bcur + 2) * B_BYTES;
                 // ---- load phase --------------------------------------------------------------------------------------------
+                constexpr int NM = TV_PP_NM < B_IT ? TV_PP_NM : B_IT, NL = B_IT - NM;   // slab pieces from the MFMA / load phase
+                const bool b_go = (tap + 2 < 9) || more;
+                const int b_koff = ((tap + 2 < 9) ? (tap + 2) * p.c_in + ch * BK : (tap + 2 - 9) * p.c_in + (ch + 1) * BK) * 2;
+                auto load_dma = [&]() {
+                    if (tap < ATAPS && tap < A_IT && more) issue_a(anxt, tap, ch + 1);
+                    if (b_go) {
+#pragma unroll
+                        for (int it = 0; it < NL; ++it) issue_b_piece(bfill, it, b_koff);
+                    }
+                };
                 __builtin_amdgcn_s_barrier();
+                TV_T(1);
+                if constexpr (TV_PP_DMA_FIRST) {
+                    load_dma();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 int hpb = hp_base;
                 asm volatile("" : "+v"(hpb));   // pin the address arithmetic to this tap
 #pragma unroll
@@ -1015,30 +1036,40 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                     for (int j = 0; j < NF; ++j) fb[kk][j] = *(const bf16x8*)(bslot + b_row_off + j * 4 * (BK * 2) + coff);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const bool b_go = (tap + 2 < 9) || more;
-                if (tap < ATAPS && tap < A_IT && more) issue_a(anxt, tap, ch + 1);
-                if (b_go) {
-                    const int b_koff = ((tap + 2 < 9) ? (tap + 2) * p.c_in + ch * BK : (tap + 2 - 9) * p.c_in + (ch + 1) * BK) * 2;
-#pragma unroll
-                    for (int it = 0; it < B_IT; ++it) issue_b_piece(bfill, it, b_koff);
+                TV_T(3);
+                if constexpr (!TV_PP_DMA_FIRST) {
+                    load_dma();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                TV_T(2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers: the slot may be refilled two barriers on
-                if (more) wait_vmcnt<B_IT + nsure(tap)>();          // everything issued in EARLIER load phases has landed
-                else if (tap + 2 < 9) wait_vmcnt<B_IT>();
+                // everything issued BEFORE this load phase (the previous load phase and the MFMA phase after it) has landed
+                if (more) wait_vmcnt<NL + nsure(tap)>();
+                else if (tap + 2 < 9) wait_vmcnt<NL>();
                 else wait_vmcnt<0>();
+                TV_T(0);
                 // ---- MFMA phase --------------------------------------------------------------------------------------------
                 __builtin_amdgcn_s_barrier();
+                TV_T(5);
                 __builtin_amdgcn_s_setprio(1);
+                constexpr int NMF2 = 2 * MF * NF, MGAP = NM > 0 ? NMF2 / (NM + 1) : NMF2 + 1;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int i = 0; i < MF; ++i)
 #pragma unroll
-                        for (int j = 0; j < NF; ++j)
+                        for (int j = 0; j < NF; ++j) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+                            const int idx = (kk * MF + i) * NF + j;
+                            if (NM > 0 && idx % MGAP == MGAP - 1 && idx / MGAP < NM) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (b_go) issue_b_piece(bfill, NL + idx / MGAP, b_koff);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                TV_T(4);
                 bcur = (bcur + 1 == BST) ? 0 : bcur + 1;
             });
         }

@@ -237,8 +237,9 @@ def _rank_main(rank, world, port, q):
         return vae_bench_loss(recon, xb, mu, logvar)
     counters = {}
     loss = train_step(ddp, opt, x[s:s + c], 1, forward_loss, None, 4, counters)     # 2 micro-batches: no_sync + sync
-    t = loss.detach().clone()
+    t = loss.detach().clone()      # each rank's value is weighted by world_size (DDP averages): the mean over ranks is the loss
     dist.all_reduce(t)
+    t /= world
     grads = {k: p.grad.detach().float().cpu().numpy().copy() for k, p in m.named_parameters()}
     if rank == 0:
         q.put((float(t), float(counters["grad_norm"]), grads))

@@ -7,6 +7,8 @@ The probe build (-DTV_PROBE) brackets the phases of the main loop with s_memtime
 spent   0 waiting for the DMA (vmcnt)   1 at the block barrier   2 issuing the next DMA   3 fragment reads (to lgkmcnt 0)
         4 MFMA issue   5 (loop exit)   6 epilogue.
 Sixteen sampled blocks dump their counters; the timers serialise the phases a little, so read shares, not absolutes.
+Ping-pong build (-DTV_HALO_PP=1): 1 = wait at the barrier that opens the load phase, 3 = fragment reads (issue + return),
+2 = DMA issue, 0 = vmcnt wait, 5 ("exit") = wait at the barrier that opens the MFMA phase, 4 = the 48 MFMAs.
 """
 import os
 import subprocess
