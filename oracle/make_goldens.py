@@ -383,6 +383,54 @@ def extra():
         json.dump(res, f, indent=0)
 
 
+NANO = dict(depths=[1, 1, 1], base_dims=[32, 32, 64], mlp_ratio=1.0, head_dim=64)    # 0.44 M parameters, compression ratio 4
+
+
+def checkpoint():
+    """A checkpoint file written from the REFERENCE model in the reference trainer's format (R/train.py:753-769:
+    {'epoch', 'global_step', 'model_state_dict', 'optimizer_state_dict', 'args'}, torch.save) after one real optimizer step
+    (fp32 CPU, AdamW lr 1e-3 betas (0.9, 0.95) wd 0.01, clip 1.0, L1 + 1e-8 KL), plus what the reference does NEXT: the loss
+    of its second step and samples of the parameters / moments after it -- so a test can resume from the file with the HIP
+    model + transvae.optim.FusedAdamW and must land where the reference lands."""
+    R = import_reference()
+    model = R["TransVAE"](config=dict(NANO), variant="nano", compression_ratio=4, latent_dim=4)
+    load_filled(model, "")
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.01)
+    orig = torch.randn_like
+    losses = []
+    for step in range(2):
+        x = filler.rand_input(f"nano.x{step}", (2, 3, 32, 32))
+        eps = filler.randn_input(f"nano.eps{step}", (2, 4, 8, 8))
+        torch.randn_like = lambda t, **kw: eps.to(t.dtype)
+        try:
+            recon, mu, logvar = model(x)
+        finally:
+            torch.randn_like = orig
+        loss = O.bench_loss(recon, x, mu, logvar)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        losses.append(float(loss))
+        if step == 0:
+            ckpt = {"epoch": 0, "global_step": 1, "model_state_dict": model.state_dict(),
+                    "optimizer_state_dict": opt.state_dict(),
+                    "args": {"variant": "nano", "compression_ratio": 4, "latent_dim": 4, "learning_rate": 1e-3, "grad_clip": 1.0}}
+            torch.save(ckpt, os.path.join(OUT, "ref_checkpoint_nano.pth"))
+    expect = {"loss_step0": losses[0], "loss_step1": losses[1], "params": {}, "exp_avg": {}}
+    names = [k for k, _ in model.named_parameters()]
+    for i, (k, p) in enumerate(model.named_parameters()):
+        if i % 7 == 0 or k in ("encoder.conv_in.weight", "decoder.conv_out.weight"):
+            flat = p.detach().flatten()
+            idx = torch.randperm(flat.numel(), generator=torch.Generator().manual_seed(zlib_crc(k)))[:16]
+            expect["params"][k] = {"idx": idx.tolist(), "val": flat[idx].tolist()}
+            expect["exp_avg"][k] = {"idx": idx.tolist(), "val": opt.state[p]["exp_avg"].flatten()[idx].tolist()}
+    expect["param_order"] = names
+    with open(os.path.join(OUT, "ref_checkpoint_nano_expect.json"), "w") as f:
+        json.dump(expect, f)
+    print("reference checkpoint written; losses", losses)
+
+
 def zlib_crc(k: str) -> int:
     import zlib
     return zlib.crc32(k.encode()) & 0x7FFFFFFF
@@ -393,5 +441,7 @@ if __name__ == "__main__":
         large()
     elif "--extra" in sys.argv:
         extra()
+    elif "--checkpoint" in sys.argv:
+        checkpoint()
     else:
         main()

@@ -136,3 +136,57 @@ def test_checkpoint_reference_format_round_trip(tmp_path):
     torch.save(ref_like, path)
     meta = load_checkpoint(path, m2, opt2)
     assert meta["global_step"] == 0
+
+
+def test_reference_written_checkpoint_loads_and_round_trips(golden_dir, tmp_path):
+    """SURVEY 8f-4 with a file the REFERENCE wrote (tests/golden/ref_checkpoint_nano.pth: its own model class, one AdamW
+    step, the dictionary of R/train.py:753-769; minted by `oracle/make_goldens.py --checkpoint`): it loads into this build's
+    model and optimizer key for key and bit for bit, a file written back by this build holds the same tensors, and one more
+    optimizer step through the fp32 ORACLE from the loaded state lands on the reference's own second step."""
+    import json
+    from oracle import filler
+    from transvae import TransVAE
+    from transvae.checkpoint import load_checkpoint, save_checkpoint
+    path = os.path.join(golden_dir, "ref_checkpoint_nano.pth")
+    raw = torch.load(path, weights_only=True)
+    assert set(raw) == {"epoch", "global_step", "model_state_dict", "optimizer_state_dict", "args"}
+    cfg = dict(depths=[1, 1, 1], base_dims=[32, 32, 64], mlp_ratio=1.0, head_dim=64)
+    m = TransVAE(config=dict(cfg), variant="nano", compression_ratio=4, latent_dim=4)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.01)
+    meta = load_checkpoint(path, m, opt)
+    assert meta["epoch"] == 0 and meta["global_step"] == 1 and meta["args"]["variant"] == "nano"
+    assert list(m.state_dict()) == list(raw["model_state_dict"])
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, raw["model_state_dict"][k]), k
+    for i, p in enumerate(m.parameters()):
+        st, rs = opt.state[p], raw["optimizer_state_dict"]["state"][i]
+        assert torch.equal(st["exp_avg"], rs["exp_avg"]) and torch.equal(st["exp_avg_sq"], rs["exp_avg_sq"])
+        assert float(st["step"]) == 1.0 and st["exp_avg"].stride() == p.stride()
+    out = str(tmp_path / "back.pth")
+    save_checkpoint(m, opt, epoch=0, global_step=1, path=out, args=raw["args"])
+    back = torch.load(out, weights_only=True)
+    for k, v in raw["model_state_dict"].items():
+        assert torch.equal(back["model_state_dict"][k], v) and back["model_state_dict"][k].is_contiguous(), k
+    for i, rs in raw["optimizer_state_dict"]["state"].items():
+        assert torch.equal(back["optimizer_state_dict"]["state"][i]["exp_avg"], rs["exp_avg"])
+    assert back["optimizer_state_dict"]["param_groups"][0]["params"] == raw["optimizer_state_dict"]["param_groups"][0]["params"]
+    # resume: the reference's second step, reproduced by the oracle + torch.optim.AdamW from the loaded file
+    with open(os.path.join(golden_dir, "ref_checkpoint_nano_expect.json")) as f:
+        exp = json.load(f)
+    sd = {k: v.clone().requires_grad_(not k.endswith("inv_freq")) for k, v in raw["model_state_dict"].items()}
+    names = [k for k in sd if sd[k].requires_grad]
+    assert names == exp["param_order"]
+    params = [sd[k] for k in names]
+    o2 = torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.01)
+    o2.load_state_dict(raw["optimizer_state_dict"])
+    x = filler.rand_input("nano.x1", (2, 3, 32, 32))
+    eps = filler.randn_input("nano.eps1", (2, 4, 8, 8))
+    recon, mu, logvar = O.forward(x, sd, cfg, eps)
+    loss = O.bench_loss(recon, x, mu, logvar)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(params, 1.0)
+    o2.step()
+    assert abs(float(loss) - exp["loss_step1"]) < 1e-5 * exp["loss_step1"]
+    for k, e in exp["params"].items():
+        got = sd[k].detach().flatten()[e["idx"]]
+        assert torch.allclose(got, torch.tensor(e["val"]), rtol=1e-4, atol=1e-6), k

@@ -411,3 +411,58 @@ def test_fused_l1_kl_loss_matches_the_reference_formulas(variant):
         assert float((got.cpu().double() - ref).norm()) < 1e-5 * float(ref.norm()) + 1e-12
     with pytest.raises(ValueError, match="external networks"):
         TransVAELoss(lpips_weight=1.0)
+
+
+def test_resume_from_a_reference_written_checkpoint(golden_dir):
+    """SURVEY 8f-4 on the GPU: tests/golden/ref_checkpoint_nano.pth (written by the reference model + torch AdamW after ITS
+    first step, R/train.py:753-769) is loaded into the HIP model and transvae.optim.FusedAdamW; the next step, on the
+    reference's own second batch, must land where the reference landed: loss within the bf16 tier, Adam moments and
+    parameters at the sampled positions within the update's own size."""
+    import json
+    from transvae import TransVAE
+    from transvae.checkpoint import load_checkpoint, save_checkpoint
+    from transvae.optim import FusedAdamW
+    from transvae.parallel import clip_and_step
+    cfg = dict(depths=[1, 1, 1], base_dims=[32, 32, 64], mlp_ratio=1.0, head_dim=64)
+    m = TransVAE(config=dict(cfg), variant="nano", compression_ratio=4, latent_dim=4).to(DEV)
+    opt = FusedAdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.95), weight_decay=0.01)
+    path = os.path.join(golden_dir, "ref_checkpoint_nano.pth")
+    meta = load_checkpoint(path, m, opt, map_location=DEV)
+    assert meta["global_step"] == 1
+    raw = torch.load(path, weights_only=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), raw["model_state_dict"][k]), k
+    assert float(opt._ctrl[0]) == 1.0
+    with open(os.path.join(golden_dir, "ref_checkpoint_nano_expect.json")) as f:
+        exp = json.load(f)
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    x = filler.rand_input("nano.x1", (2, 3, 32, 32)).to(DEV)
+    eps = filler.randn_input("nano.eps1", (2, 4, 8, 8)).to(DEV)
+    m.train()
+    recon, mu, logvar = m(x, eps=eps)
+    loss = O.bench_loss(recon, x, mu, logvar)
+    loss.backward()
+    clip_and_step(list(m.parameters()), opt, 1.0)
+    assert abs(float(loss) - exp["loss_step1"]) < 1e-2 * exp["loss_step1"], (float(loss), exp["loss_step1"])
+    params = dict(m.named_parameters())
+    num = den = 0.0
+    for k, e in exp["params"].items():
+        idx = torch.tensor(e["idx"], device=DEV)
+        got = params[k].detach().flatten()[idx].double().cpu()
+        ref = torch.tensor(e["val"], dtype=torch.float64)
+        start = before[k].flatten()[idx].double().cpu()
+        num += float((got - ref).norm() ** 2)
+        den += float((ref - start).norm() ** 2)
+        m_got = opt.state[params[k]]["exp_avg"].flatten()[idx].double().cpu()
+        m_ref = torch.tensor(exp["exp_avg"][k]["val"], dtype=torch.float64)
+        assert float((m_got - m_ref).norm()) < 0.25 * float(m_ref.norm()) + 1e-9, k      # (16 samples of a bf16-noisy gradient)
+    assert (num / den) ** 0.5 < 0.25, (num / den) ** 0.5      # the step taken agrees with the reference's step
+    assert float(opt._ctrl[0]) == 2.0
+    # written back in the reference's format: step counters are plain scalars again
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "back.pth")
+        save_checkpoint(m, opt, epoch=0, global_step=2, path=out, args=meta["args"])
+        back = torch.load(out, weights_only=True)
+        assert float(back["optimizer_state_dict"]["state"][0]["step"]) == 2.0
+        assert set(back["optimizer_state_dict"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
