@@ -77,13 +77,13 @@ struct IgemmArgs {
 #define TV_SETPRIO 1           // waves 4-7 (the arbitration losers on every SIMD) run at priority 1
 #endif
 #ifndef TV_HALO_PP
-#define TV_HALO_PP 0       // wave-group ping-pong main loop of the 8-wave halo tiles (see conv3x3_halo_kernel)
-#endif
+#define TV_HALO_PP 1       // wave-group ping-pong main loop of the 8-wave halo tiles with a 3-deep weight ring (see conv3x3_halo_kernel):
+#endif                     // +8-10 % on the 192-channel 3x3 layers over the lockstep pipelined loop (tools/probes/ab_lib.py)
 #ifndef TV_PP_NM
 #define TV_PP_NM 0         // ping-pong: weight-slab DMA pieces (of B_IT per wave and step) issued from the MFMA phase
 #endif
 #ifndef TV_PP_DMA_FIRST
-#define TV_PP_DMA_FIRST 0  // ping-pong: DMA pieces of a load phase before (1) or after (0) its fragment reads
+#define TV_PP_DMA_FIRST 0  // ping-pong: DMA pieces of a load phase before (1) or after (0) its fragment reads; 2 = threaded between them
 #endif
 #ifndef TV_NO_PINGPONG
 #define TV_NO_PINGPONG 1   // ping-pong main loop of the 8-wave tiles: measured, not (yet) a win -- see DESIGN.md
@@ -1009,21 +1009,24 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                 constexpr int NM = TV_PP_NM < B_IT ? TV_PP_NM : B_IT, NL = B_IT - NM;   // slab pieces from the MFMA / load phase
                 const bool b_go = (tap + 2 < 9) || more;
                 const int b_koff = ((tap + 2 < 9) ? (tap + 2) * p.c_in + ch * BK : (tap + 2 - 9) * p.c_in + (ch + 1) * BK) * 2;
+                // The weight pieces go out FIRST, the halo piece (HBM latency) last: vmcnt retires in issue order, so a slow halo
+                // piece in front of them would hold back the wait for the (L2-resident) weight slab behind it.
                 auto load_dma = [&]() {
-                    if (tap < ATAPS && tap < A_IT && more) issue_a(anxt, tap, ch + 1);
                     if (b_go) {
 #pragma unroll
                         for (int it = 0; it < NL; ++it) issue_b_piece(bfill, it, b_koff);
                     }
+                    if (tap < ATAPS && tap < A_IT && more) issue_a(anxt, tap, ch + 1);
                 };
                 __builtin_amdgcn_s_barrier();
                 TV_T(1);
-                if constexpr (TV_PP_DMA_FIRST) {
+                if constexpr (TV_PP_DMA_FIRST == 1) {
                     load_dma();
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 int hpb = hp_base;
                 asm volatile("" : "+v"(hpb));   // pin the address arithmetic to this tap
+#ifndef TV_ABL_NO_LDSREAD
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -1031,27 +1034,53 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                         const int hp = hpb + i * HWD + toff;
                         fa[kk][i] = *(const bf16x8*)(acur + hp * (BK * 2) + (((kk * 4 + fq) ^ (hp & 7)) << 4));
                     }
+                    if constexpr (TV_PP_DMA_FIRST == 2) {   // threaded: a DMA piece after each group of reads
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (b_go && kk < NL) issue_b_piece(bfill, kk, b_koff);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     const int coff = ((kk * 4 + fq) ^ sw) * 16;
 #pragma unroll
                     for (int j = 0; j < NF; ++j) fb[kk][j] = *(const bf16x8*)(bslot + b_row_off + j * 4 * (BK * 2) + coff);
+                    if constexpr (TV_PP_DMA_FIRST == 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (kk == 0) {
+                            if (b_go && 2 < NL) issue_b_piece(bfill, 2, b_koff);
+                        } else if (tap < ATAPS && tap < A_IT && more) {
+                            issue_a(anxt, tap, ch + 1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
+#else
+                if (tap == 0 && ch == 0) {
+                    for (int kk = 0; kk < 2; ++kk) {
+                        for (int i = 0; i < MF; ++i) { fa[kk][i] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(fa[kk][i])); }
+                        for (int j = 0; j < NF; ++j) { fb[kk][j] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(fb[kk][j])); }
+                    }
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 TV_T(3);
-                if constexpr (!TV_PP_DMA_FIRST) {
+                if constexpr (TV_PP_DMA_FIRST == 0) {
                     load_dma();
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 TV_T(2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments in registers: the slot may be refilled two barriers on
-                // everything issued BEFORE this load phase (the previous load phase and the MFMA phase after it) has landed
-                if (more) wait_vmcnt<NL + nsure(tap)>();
+                // The weight pieces of the PREVIOUS load phase (and of the MFMA phase after it) have landed; still in flight may be,
+                // in issue order: [that phase's halo piece] [this phase's weight pieces] [this phase's halo piece].  The halo
+                // pieces of a chunk are all retired by tap 7 (taps 6-8 issue none).
+                if (more) wait_vmcnt<nsure(tap - 1) + NL + nsure(tap)>();
                 else if (tap + 2 < 9) wait_vmcnt<NL>();
                 else wait_vmcnt<0>();
                 TV_T(0);
                 // ---- MFMA phase --------------------------------------------------------------------------------------------
                 __builtin_amdgcn_s_barrier();
                 TV_T(5);
+#ifndef TV_PP_NOPRIO
                 __builtin_amdgcn_s_setprio(1);
+#endif
                 constexpr int NMF2 = 2 * MF * NF, MGAP = NM > 0 ? NMF2 / (NM + 1) : NMF2 + 1;
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk)
@@ -1471,7 +1500,12 @@ int launch_halo(IgemmArgs& a, hipStream_t s) {
     // (256x192 halo tiles with several N tiles run the 2-deep weight ring, which recomputes its DMA offsets: slower than
     //  128x128 there -- only the one-N-tile case takes 192 by choice)
     int bn = pick_tile(a.M, N, h16, h16 && (N == 192 || N % 128 != 0), &bm);
+    // 256x192 tiles on the ping-pong loop with the 3-deep weight ring beat every other choice wherever N is a multiple of
+    // 192 (tools/probes/ab_lib.py, 64 images): 384@64 1072 -> 1273 TFLOP/s over 128x128 tiles, 768@32 1394 -> 1498 and
+    // 1536@16 1220 -> 1532 over 256x256 tiles
+    if (TV_HALO_PP && N % 192 == 0 && h16 && g_cfg_bn == 0 && g_halo_ring == 3 && !g_halo_w4) { bn = 192; bm = 256; }
     if (g_cfg_bn == 256 && N % 256 == 0 && h16) { bn = 256; bm = 256; }
+    else if (g_cfg_bn == 192 && N % 192 == 0 && h16) { bn = 192; bm = 256; }
     else if (g_cfg_bn == 128) { bn = (N % 192 == 0 && N % 128 != 0) ? 192 : 128; bm = 128; }
     if (g_cfg_bm) bm = g_cfg_bm;
     if (bm == 256 && !h16) bm = 128;
@@ -1479,7 +1513,7 @@ int launch_halo(IgemmArgs& a, hipStream_t s) {
         a.tiles_n = N / 192;
         // weight ring 3 deep only where measured faster (one N tile: res192@256/@128); 2 everywhere else
         if (bm == 256 && g_halo_w4) return launch_halo_ring<256, 192, 2, 2>(a, (g_halo_ring == 3 && a.tiles_n == 1) || g_halo_ring == 4 ? 3 : 2, s);
-        if (bm == 256) return launch_halo_ring<256, 192, 4, 2>(a, (g_halo_ring == 3 && a.tiles_n == 1) || g_halo_ring == 4 ? 3 : 2, s);
+        if (bm == 256) return launch_halo_ring<256, 192, 4, 2>(a, (g_halo_ring == 3 && (a.tiles_n == 1 || TV_HALO_PP)) || g_halo_ring == 4 ? 3 : 2, s);
         return launch_halo_ring<128, 192, 2, 2>(a, g_halo_ring == 4 ? 3 : 2, s);
     }
     if (bn == 256 && bm == 256) {

@@ -13,6 +13,7 @@ from transvae.hip import _lib as L
 dev = torch.device("cuda:0")
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 quick = len(sys.argv) > 2 and sys.argv[2] == "quick"     # only the 192-channel layers, forward and data gradient
+wide = len(sys.argv) > 2 and sys.argv[2] == "wide"       # only the 384 / 768 / 1536-channel layers, forward and data gradient
 bf = torch.bfloat16
 
 
@@ -26,8 +27,12 @@ def tm(fn, it=10):
 
 
 print("library:", L.SO_PATH)
+if os.environ.get("TV_AB_HALO"):
+    L.load().tv_set_igemm_halo(int(os.environ["TV_AB_HALO"]))
+if os.environ.get("TV_AB_CFG"):      # bm,bn,stages,bk
+    L.load().tv_set_igemm_config(*[int(v) for v in os.environ["TV_AB_CFG"].split(",")])
 g = torch.Generator(device=dev).manual_seed(0)
-for (hw, Cc) in ([(256, 192), (128, 192)] if quick else [(256, 192), (128, 192), (64, 384), (32, 768), (16, 1536)]):
+for (hw, Cc) in ([(256, 192), (128, 192)] if quick else ([(64, 384), (32, 768), (16, 1536)] if wide else [(256, 192), (128, 192), (64, 384), (32, 768), (16, 1536)])):
     x = torch.randn(mb, hw, hw, Cc, device=dev, generator=g).to(bf)
     w = torch.randn(Cc, 3, 3, Cc, device=dev, generator=g) * (9 * Cc) ** -0.5
     b = torch.randn(Cc, device=dev, generator=g) * 0.1
@@ -39,7 +44,7 @@ for (hw, Cc) in ([(256, 192), (128, 192)] if quick else [(256, 192), (128, 192),
              ("fwd gelu", lambda: ops.conv_forward(x, w, b, None, "c3s1", L.ACT_GELU, "deriv")[0]),
              ("dgrad", lambda: ops.conv_dgrad(geo, w, res, x.shape)),
              ("dgrad*deriv", lambda: ops.conv_dgrad(geo, w, res, x.shape, None, x, L.ACT_DERIV))]
-    for name, fn in (cases[:1] + cases[3:4] if quick else cases):
+    for name, fn in (cases[:1] + cases[3:4] if (quick or wide) else cases):
         t = min(tm(fn), tm(fn))
         y = fn().float()
         print(f"c3s1 {Cc:5d}@{hw:<4d} {name:12s} {t:7.3f} ms {f / t / 1e9:6.0f} TF/s   sum {float(y.sum()):.6e} abs {float(y.abs().sum()):.6e}", flush=True)
