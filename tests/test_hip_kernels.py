@@ -131,6 +131,53 @@ def test_conv_forward_backward(case, dma):
         _lib.load().tv_set_dma(1)
 
 
+WGRAD3_CASES = [
+    # (B, H, W, Cin, Cout): 3x3 / stride-1 weight gradient through the kx-triple kernel -- image-row segments of 16 / 32 /
+    # 64 pixels (W = 16, 32, >= 64), several segments per K-step, several K-steps, split-K chunks, all three tile shapes
+    (1, 16, 16, 192, 192),     # 192x64 tiles, four 16-pixel segments per K-step
+    (3, 16, 16, 64, 128),      # 64x64 tiles, batch 3
+    (2, 32, 32, 128, 256),     # 128x128 tiles, two 32-pixel segments per K-step
+    (1, 16, 64, 192, 192),     # non-square: one 64-pixel segment = one image row
+    (2, 32, 128, 64, 64),      # two K-steps per image row
+    (1, 64, 256, 128, 128),    # four K-steps per image row
+    (4, 64, 64, 192, 384),     # Cout 384 -> 128x... no: 384 % 128 == 0 and Cin 192 % 128 != 0 -> 64x64 tiles; split-K chunks
+    (5, 128, 128, 192, 192),   # 81 920 pixels: split over many chunks, XCD-grouped order, ragged last chunk
+]
+
+
+@pytest.mark.parametrize("case", WGRAD3_CASES, ids=["x".join(map(str, c)) for c in WGRAD3_CASES])
+def test_wgrad_kx_triple(case):
+    """tv_wgrad_tn on 3x3 / stride-1 layers (kx-triple kernel: the three kx taps share the staged tiles, x-padding from the
+    halo rows of each image-row segment; opt-in: tv_set_wgrad_config(0, 0, -6)) against fp32 PyTorch on the same
+    bf16-rounded operands, and against the default single-tap kernel on the same inputs."""
+    from transvae.hip import ops, _lib
+    B, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = r16(torch.randn(B, H, W, Ci, generator=g))
+    gy = r16(torch.randn(B, H, W, Co, generator=g))
+    w = torch.zeros(Co, 3, 3, Ci)
+    xn = x.permute(0, 3, 1, 2).clone().requires_grad_(False)
+    wn = w.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    bn = torch.zeros(Co, requires_grad=True)
+    F.conv2d(xn, wn, bn, padding=1).backward(gy.permute(0, 3, 1, 2))
+    ref_dw = wn.grad.permute(0, 2, 3, 1)
+    xd, gd, wd = x.to(dev(), BF), gy.to(dev(), BF), w.to(dev())
+    geo = ops._Geo("c3s1", xd, wd)
+    lib = _lib.load()
+    outs = []
+    for single in (False, True):
+        lib.tv_set_wgrad_config(0, 0, 0 if single else -6)
+        try:
+            dw, db = ops.conv_wgrad(geo, wd, xd, gd, True)
+            torch.cuda.synchronize()
+        finally:
+            lib.tv_set_wgrad_config(0, 0, 0)
+        outs.append((dw.cpu(), db.cpu()))
+        assert rel(dw, ref_dw) < 1e-2, ("single-tap" if single else "triple", rel(dw, ref_dw))
+        assert rel(db, bn.grad) < 1e-2
+    assert rel(outs[0][0], outs[1][0]) < 1e-4       # same bf16 products, fp32 sums in a different order
+
+
 DERIV_CASES = [
     ("linear", (300, 256), (384,), "gelu", False),
     ("linear", (130, 96), (192,), "silu", True),
