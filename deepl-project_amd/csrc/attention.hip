@@ -132,9 +132,23 @@ struct AttnArgs {
     float* lse;
     float* delta;
     const char* zeros;
+    const float* rope;   // backward only: table [N][4][32]; dq / dk are stored as gradients w.r.t. the UN-rotated projections
     int B, N, heads;
     float scale;
 };
+
+// adjoint of the reference's (non-orthogonal) RoPE 2x2 on four consecutive channels ch0 .. ch0+3 of a head (two pairs):
+//   forward  o[2p] = a cos1 - b sin1,  o[2p+1] = a sin2 + b cos2      (R/transvae/modules/attention.py:156-197)
+//   adjoint  a' = ga cos1 + gb sin2,   b' = -ga sin1 + gb cos2
+__device__ __forceinline__ void rope_adjoint4(float (&v)[4], const float* tab_row, int ch0) {
+    const float* tb = tab_row + (ch0 >> 1);
+    const float c1a = tb[0], c1b = tb[1], s1a = tb[32], s1b = tb[33], c2a = tb[64], c2b = tb[65], s2a = tb[96], s2b = tb[97];
+    const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
+    v[0] = a0 * c1a + b0 * s2a;
+    v[1] = -a0 * s1a + b0 * c2a;
+    v[2] = a1 * c1b + b1 * s2b;
+    v[3] = -a1 * s1b + b1 * c2b;
+}
 
 constexpr int KV_TILE = 64 * 128;  // bytes of one [64][64] bf16 tile
 
@@ -420,8 +434,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16x4 v = {(bf16)(dqt[db][4 * g] * p.scale), (bf16)(dqt[db][4 * g + 1] * p.scale),
-                            (bf16)(dqt[db][4 * g + 2] * p.scale), (bf16)(dqt[db][4 * g + 3] * p.scale)};
+                float f[4] = {dqt[db][4 * g] * p.scale, dqt[db][4 * g + 1] * p.scale, dqt[db][4 * g + 2] * p.scale, dqt[db][4 * g + 3] * p.scale};
+                if (p.rope) rope_adjoint4(f, p.rope + (size_t)qi * 128, db * 32 + 8 * g + 4 * h);
+                bf16x4 v = {(bf16)f[0], (bf16)f[1], (bf16)f[2], (bf16)f[3]};
                 *(bf16x4*)(row + db * 32 + 8 * g + 4 * h) = v;
             }
     }
@@ -543,8 +558,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16x4 a = {(bf16)(dkt[db][4 * g] * p.scale), (bf16)(dkt[db][4 * g + 1] * p.scale),
-                            (bf16)(dkt[db][4 * g + 2] * p.scale), (bf16)(dkt[db][4 * g + 3] * p.scale)};
+                float f[4] = {dkt[db][4 * g] * p.scale, dkt[db][4 * g + 1] * p.scale, dkt[db][4 * g + 2] * p.scale, dkt[db][4 * g + 3] * p.scale};
+                if (p.rope) rope_adjoint4(f, p.rope + (size_t)ki * 128, db * 32 + 8 * g + 4 * h);
+                bf16x4 a = {(bf16)f[0], (bf16)f[1], (bf16)f[2], (bf16)f[3]};
                 bf16x4 v = {(bf16)dvt[db][4 * g], (bf16)dvt[db][4 * g + 1], (bf16)dvt[db][4 * g + 2], (bf16)dvt[db][4 * g + 3]};
                 *(bf16x4*)(krow + db * 32 + 8 * g + 4 * h) = a;
                 *(bf16x4*)(vrow + db * 32 + 8 * g + 4 * h) = v;
@@ -575,15 +591,15 @@ extern "C" int tv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, i
     return TV_OK;
 }
 
-extern "C" int tv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, float* dq_acc,
+extern "C" int tv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, const float* rope_tab,
                            void* dqkv, int B, int N, int heads, float scale, void* stream) {
-    (void)dq_acc;  // reserved (an atomics-based dq accumulation would use it); may be NULL
     if (attn_check("tv_attn_bwd", B, N, heads, scale)) return TV_ERR_ARG;
     TV_CHECK_ARG(qkv && o && d_o && lse && delta && dqkv, "tv_attn_bwd: null pointer");
     if (tv_init() != TV_OK) return TV_ERR_INIT;
     AttnArgs a{};
     a.qkv = (const bf16*)qkv; a.o = (const bf16*)o; a.d_o = (const bf16*)d_o; a.out = (bf16*)dqkv;
     a.lse = const_cast<float*>(lse); a.delta = delta; a.zeros = (const char*)tv_zero_page();
+    a.rope = rope_tab;
     a.B = B; a.N = N; a.heads = heads; a.scale = scale;
     hipStream_t s = (hipStream_t)stream;
     const long long tot = (long long)B * N * heads * 8;

@@ -45,6 +45,8 @@ struct IgemmArgs {
     int act;
     int aux_act;
     int pre_deriv;     // pre receives act'(pre-activation) (TV_ACT_SAVE_DERIV)
+    const float* rope; // QKV projection: RoPE table [tokens][4][32] applied to output columns < rope_cols (q and k thirds)
+    int rope_tokens, rope_cols;
     int hw_shift, w_shift;  // log2 of h_out*w_out / w_out when both are powers of two, else -1
     unsigned x_bytes, w_bytes;  // MODE 2: extents of the two buffers (< 2 GiB)
 };
@@ -248,6 +250,18 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
             const f32x4 v0 = *(const f32x4*)(ebuf + rl * ERS + c8 * 32);
             const f32x4 v1 = *(const f32x4*)(ebuf + rl * ERS + c8 * 32 + 16);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (p.rope && n < p.rope_cols) {
+                // RoPE2D of the reference on the unrounded projection (R/transvae/modules/attention.py:156-197): the lane's 8
+                // channels are pairs 4v .. 4v+3 of one head; out[2p] = a cos1 - b sin1, out[2p+1] = a sin2 + b cos2
+                const float* tb = p.rope + (size_t)(m % p.rope_tokens) * 128 + ((n & 63) >> 1);
+                const f32x4 c1 = *(const f32x4*)(tb), s1 = *(const f32x4*)(tb + 32), c2 = *(const f32x4*)(tb + 64), s2 = *(const f32x4*)(tb + 96);
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const float a = v[2 * pr], bb = v[2 * pr + 1];
+                    v[2 * pr] = a * c1[pr] - bb * s1[pr];
+                    v[2 * pr + 1] = a * s2[pr] + bb * c2[pr];
+                }
+            }
             bf16x8 z;
             const bool save_deriv = p.pre && p.pre_deriv;
             if (save_deriv) {   // save act'(pre-activation): the backward epilogue then is one multiply per element
@@ -1351,6 +1365,7 @@ bool g_epi_modes = true;   // compile-time epilogue forms (tv_set_igemm_epilogue
 
 // which epilogue form a call takes (see epilogue<>): 1 = residual add only, 2 = saved-derivative multiply, 0 = the rest
 int epilogue_mode(const IgemmArgs& a) {
+    if (a.rope) return 0;
     if (!g_epi_modes || a.shuffle || a.pre || ((long long)a.M * a.ldo >> 3) >= 0xffffffffll) return 0;
     if (a.aux) return (a.aux_act == TV_ACT_DERIV && !a.res) ? 2 : 0;
     return (a.res && a.act == TV_ACT_NONE) ? 1 : 0;
@@ -1570,8 +1585,21 @@ extern "C" int tv_set_igemm_config(int bm, int bn, int stages, int bk) {
     return 0;
 }
 
+struct RopeSpec {
+    const float* tab;
+    int tokens, cols;
+};
 static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
-                         void* pre_act, void* out, const void* aux, int aux_act, void* stream);
+                         void* pre_act, void* out, const void* aux, int aux_act, void* stream, RopeSpec rope = RopeSpec{nullptr, 0, 0});
+
+extern "C" int tv_igemm_nt_rope(const tv_conv_desc* d, const void* x, const void* w, const float* bias, void* out,
+                                const float* rope_tab, int tokens_per_image, int rope_cols, void* stream) {
+    TV_CHECK_ARG(d && rope_tab && tokens_per_image > 0 && rope_cols > 0 && rope_cols % 64 == 0 && rope_cols <= d->c_out,
+                 "tv_igemm_nt_rope: rope_cols must be a positive multiple of 64 (whole heads) within c_out");
+    TV_CHECK_ARG(d->store_shuffle == 0 && (d->act & ~TV_ACT_SAVE_DERIV) == TV_ACT_NONE, "tv_igemm_nt_rope: plain projection only");
+    TV_CHECK_ARG(((long long)d->batch * d->h_out * d->w_out) % tokens_per_image == 0, "tv_igemm_nt_rope: rows must be whole images");
+    return igemm_nt_impl(d, x, w, bias, nullptr, nullptr, out, nullptr, TV_ACT_NONE, stream, RopeSpec{rope_tab, tokens_per_image, rope_cols});
+}
 
 extern "C" int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, const float* bias,
                            const void* residual, void* pre_act, void* out, void* stream) {
@@ -1586,7 +1614,7 @@ extern "C" int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const v
 }
 
 static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
-                         void* pre_act, void* out, const void* aux, int aux_act, void* stream) {
+                         void* pre_act, void* out, const void* aux, int aux_act, void* stream, RopeSpec rope) {
     TV_CHECK_ARG(d && x && w && out, "tv_igemm_nt: null pointer");
     TV_CHECK_ARG(d->c_in > 0 && d->c_in % 32 == 0, "tv_igemm_nt: c_in=%d must be a multiple of 32", d->c_in);
     TV_CHECK_ARG(d->c_out > 0 && d->c_out % 8 == 0, "tv_igemm_nt: c_out=%d must be a multiple of 8", d->c_out);
@@ -1629,6 +1657,9 @@ static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, co
     a.shuffle = d->store_shuffle;
     a.act = d->act & ~TV_ACT_SAVE_DERIV;
     a.pre_deriv = (d->act & TV_ACT_SAVE_DERIV) ? 1 : 0;
+    a.rope = rope.tab;
+    a.rope_tokens = rope.tokens;
+    a.rope_cols = rope.cols;
     {
         auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; };
         a.w_shift = lg(d->w_out);

@@ -198,9 +198,9 @@ class AttnBranchFn(torch.autograd.Function):
         w_rms = _c(w_rms)
         Cc = t.shape[1]
         xh = rownorm_fwd(t, w_rms, 1, eps_rms, eps_ln)
-        qkv, _, geo_q, wq = conv_forward(xh, wqkv, _c(bqkv), None, "linear", NONE, False)
-        if tab is not None:
-            L.check(lib.tv_rope_qk(_p(qkv), _p(tab), B, N, heads, 0, _stream()), "tv_rope_qk")
+        # QKV projection with RoPE in the GEMM epilogue (q and k thirds rotated before the one rounding to bf16)
+        qkv, _, geo_q, wq = conv_forward(xh, wqkv, _c(bqkv), None, "linear", NONE, False,
+                                         rope=(tab, N, 2 * Cc) if tab is not None else None)
         o = torch.empty((B * N, Cc), dtype=BF16, device=t.device)
         lse = torch.empty((B, heads, N), dtype=torch.float32, device=t.device)
         L.check(lib.tv_attn_fwd(_p(qkv), _p(o), _p(lse), B, N, heads, scale, _stream()), "tv_attn_fwd")
@@ -221,10 +221,9 @@ class AttnBranchFn(torch.autograd.Function):
         dwp, dbp = _wg(ctx, 4, 5, geo_p, wp, o, g)
         delta = torch.empty((B, heads, N), dtype=torch.float32, device=t.device)
         dqkv = torch.empty_like(qkv)
-        L.check(lib.tv_attn_bwd(_p(qkv), _p(o), _p(do), _p(lse), _p(delta), None, _p(dqkv), B, N, heads, scale, _stream()),
+        # (the adjoint of RoPE is applied to dq / dk inside the attention-backward stores)
+        L.check(lib.tv_attn_bwd(_p(qkv), _p(o), _p(do), _p(lse), _p(delta), _p(tab), _p(dqkv), B, N, heads, scale, _stream()),
                 "tv_attn_bwd")
-        if tab is not None:
-            L.check(lib.tv_rope_qk(_p(dqkv), _p(tab), B, N, heads, 1, _stream()), "tv_rope_qk")
         dxh = conv_dgrad(geo_q, wq, dqkv, xh.shape)
         dwq, dbq = _wg(ctx, 2, 3, geo_q, wq, xh, dqkv)
         dt, dw_rms = rownorm_bwd(t, w_rms, dxh, g, 1, eps_rms, eps_ln)     # + residual gradient, fused

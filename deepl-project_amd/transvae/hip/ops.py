@@ -303,8 +303,10 @@ class _Geo:
 
 
 # ---- the three passes of one layer as plain functions (shared by ConvFn and the fused block Functions) ----
-def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre):
+def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre, rope=None):
     """Returns (out, pre_activation | None, geometry, contiguous fp32 weight).
+    rope = (table [N, 4, 32] fp32, tokens per image N, columns to rotate): 'linear' only -- the QKV projection with RoPE in
+    its epilogue (tv_igemm_nt_rope).
     want_pre = "deriv": the second tensor is act'(pre-activation) instead (pass it to conv_dgrad with
     aux_act = L.ACT_DERIV); falsy: nothing is saved."""
     _need_gpu(x, w)
@@ -331,6 +333,14 @@ def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre):
         igemm(d, x, wb, bias.repeat(4) if bias is not None else None, residual, pre, out)
         return out, pre, g, w
     wb, _ = pack_weight(w.view(g.Cout, g.KH * g.KW, g.Cin), True, False, False)
+    if rope is not None:
+        tab, tokens, cols = rope
+        _require(mode == "linear" and residual is None and pre is None and act_id == L.ACT_NONE, "rope epilogue: plain projection only")
+        _require(tab.dtype == torch.float32 and tab.is_contiguous() and tuple(tab.shape) == (tokens, 4, 32) and g.B % tokens == 0,
+                 "rope table must be contiguous fp32 [tokens, 4, 32] and the rows whole images")
+        L.check(L.load().tv_igemm_nt_rope(C.byref(g.fwd_desc(act_id)), _p(x), _p(wb), _p(bias), _p(out), _p(tab), int(tokens), int(cols),
+                                          _stream()), "tv_igemm_nt_rope")
+        return out, pre, g, w
     igemm(g.fwd_desc(act_id), x, wb, bias, residual, pre, out)
     return out, pre, g, w
 

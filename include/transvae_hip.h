@@ -87,6 +87,13 @@ typedef struct tv_conv_desc {
 int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, const float* bias,
                 const void* residual, void* pre_act, void* out, void* stream);
 
+/* The QKV projection with RoPE in its epilogue (north star: "fused RMSNorm+RoPE+QKV-proj"; R/transvae/modules/attention.py:
+ * 43-48 Linear q/k/v, :76-78 head split, :132-199 RoPE2D): out = x w^T + bias, and output columns < rope_cols (the q and k
+ * thirds, whole heads of 64) are rotated with the table of tv_rope_qk before the single rounding to bf16; row m is token
+ * m % tokens_per_image of its image. */
+int tv_igemm_nt_rope(const tv_conv_desc* d, const void* x, const void* w, const float* bias, void* out,
+                     const float* rope_tab, int tokens_per_image, int rope_cols, void* stream);
+
 /*
  * Data gradient fused with the activation backward of the PREVIOUS layer:
  *     out = (conv(x, w) + residual) * act'(aux_pre_act)
@@ -167,9 +174,11 @@ int tv_rope_qk(void* qkv, const float* tab, int B, int N, int heads, int transpo
  * qkv [B,N,3,heads,64] bf16; o [B,N,heads,64] bf16; lse [B,heads,N] fp32 (natural log). */
 int tv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int heads, float scale,
                 void* stream);
-/* dqkv [B,N,3,heads,64] bf16 from do; delta [B,heads,N] fp32 is scratch. */
+/* dqkv [B,N,3,heads,64] bf16 from do; delta [B,heads,N] fp32 is scratch.  rope_tab (may be NULL): the table of tv_rope_qk;
+ * when given, q and k in `qkv` are the ROTATED projections (tv_igemm_nt_rope) and dq / dk are stored as gradients w.r.t.
+ * the un-rotated ones (the adjoint of attention.py:156-197 applied to the fp32 accumulators in the store). */
 int tv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
-                float* dq_acc, void* dqkv, int B, int N, int heads, float scale, void* stream);
+                const float* rope_tab, void* dqkv, int B, int N, int heads, float scale, void* stream);
 
 /* elementwise ------------------------------------------------------------------------------- */
 /* dz = dy * act'(z)   (n bf16 elements, n % 8 == 0) */

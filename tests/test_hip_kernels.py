@@ -509,6 +509,52 @@ def test_rope_kernel(H, W, heads):
     assert torch.equal(dy[:, :, 2].cpu().float(), y[:, :, 2])
 
 
+@pytest.mark.parametrize("B,H,W,heads", [(2, 8, 8, 2), (1, 16, 12, 1), (1, 5, 12, 3), (2, 32, 32, 6)])
+def test_qkv_projection_with_rope_in_the_epilogue_and_adjoint_in_attention_backward(B, H, W, heads):
+    """tv_igemm_nt_rope == projection followed by the reference RoPE on q and k (fp32, oracle formula; v untouched), and
+    tv_attn_bwd(rope_tab) == tv_attn_bwd(NULL) followed by the adjoint rotation (tv_rope_qk transpose), on the same inputs."""
+    from oracle import transvae_oracle as O
+    from oracle import filler
+    from transvae.hip import ops, _lib
+    import ctypes as C
+    N, Cc = H * W, heads * 64
+    lib = _lib.load()
+    x = r16(gen(B * N, Cc, seed=1))
+    w = r16(gen(3 * Cc, Cc, seed=2) * Cc ** -0.5)
+    b = gen(3 * Cc, seed=3) * 0.1
+    tab = _rope_tab(H, W)
+    tabs = O.rope_tables(H, W, filler.inv_freq(64))
+    ref = F.linear(x, w, b).view(B, N, 3, heads, 64)
+    ref_rot = ref.clone()
+    for which in (0, 1):
+        ref_rot[:, :, which] = O.rope_apply(ref[:, :, which].permute(0, 2, 1, 3), tabs).permute(0, 2, 1, 3)
+    tabd = tab.to(dev())
+    out, _, geo, _ = ops.conv_forward(x.to(dev(), BF), w.to(dev()), b.to(dev()), None, "linear", _lib.ACT_NONE, False,
+                                      rope=(tabd, N, 2 * Cc))
+    torch.cuda.synchronize()
+    got = out.view(B, N, 3, heads, 64)
+    assert rel(got, ref_rot) < 1e-2, rel(got, ref_rot)
+    assert rel(got[:, :, 2], ref[:, :, 2]) < 1e-2                      # v: plain projection
+    # backward: fused adjoint vs separate pass
+    qkv = got.contiguous()
+    o = torch.empty((B, N, Cc), dtype=BF, device=dev())
+    lse = torch.empty((B, heads, N), dtype=torch.float32, device=dev())
+    _lib.check(lib.tv_attn_fwd(ops._p(qkv), ops._p(o), ops._p(lse), B, N, heads, 0.125, None))
+    do = gen(B, N, Cc, seed=4).to(dev(), BF)
+    res = []
+    for fused_adjoint in (True, False):
+        delta = torch.empty((B, heads, N), dtype=torch.float32, device=dev())
+        dqkv = torch.empty_like(qkv)
+        _lib.check(lib.tv_attn_bwd(ops._p(qkv), ops._p(o), ops._p(do), ops._p(lse), ops._p(delta), ops._p(tabd) if fused_adjoint else None,
+                                   ops._p(dqkv), B, N, heads, 0.125, None))
+        if not fused_adjoint:
+            _lib.check(lib.tv_rope_qk(ops._p(dqkv), ops._p(tabd), B, N, heads, 1, None))
+        torch.cuda.synchronize()
+        res.append(dqkv.float().cpu())
+    assert rel(res[0], res[1]) < 1e-2, rel(res[0], res[1])
+    assert torch.equal(res[0][:, :, 2], res[1][:, :, 2])               # dv is not rotated
+
+
 @pytest.mark.parametrize("B,H,W,heads,rope", [(2, 8, 8, 2, True), (1, 16, 12, 1, True), (2, 4, 4, 3, False),
                                               (1, 16, 16, 2, True), (1, 15, 20, 1, True), (1, 32, 32, 2, True)])
 def test_attention_fwd_bwd(B, H, W, heads, rope):
