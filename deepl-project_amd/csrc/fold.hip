@@ -1,0 +1,80 @@
+// Parameter folds of the TransVAE block, forward and backward as one launch each (train-step glue).
+//
+//   Wf[r][c] = W[r][c] * gamma[c]          bf[r] = sum_c W[r][c] * beta[c]        (beta may be NULL: no bias term)
+//
+// is how a LayerNorm / RMSNorm affine in front of a Linear disappears into the projection:
+//   Linear(LayerNorm-hat(x) * gamma + beta) = x-hat (W gamma)^T + W beta       (R/transvae/modules/attention.py:39-48,71-78)
+//   Linear(RMSNorm-hat(x) * w_rms)          = x-hat (W w_rms)^T                (R/transvae/modules/blocks.py:146-149, conv.py:85)
+// The PyTorch formulation costs ~40 launch-bound kernels per attention block and micro-batch (mul, gemv, cat and their
+// autograd twins: 1.2 % of the train step, profiles/r02_rocprof_kernel_stats.csv of the previous build); here 2.
+// Backward, one pass over the matrices:
+//   dW[r][c] = dWf[r][c] gamma[c] + dbf[r] beta[c]     dgamma[c] = sum_r dWf[r][c] W[r][c]     dbeta[c] = sum_r dbf[r] W[r][c]
+// Column sums are taken in a fixed order (one block owns 64 columns): bit-reproducible.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ Wf, float* __restrict__ bf, int R, int Cc) {
+    __shared__ float s_red[4];
+    const int r = blockIdx.x;
+    const float* w = W + (size_t)r * Cc;
+    float* o = Wf + (size_t)r * Cc;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < Cc; c += 256) {
+        const float v = w[c];
+        o[c] = v * gamma[c];
+        if (beta) acc = fmaf(v, beta[c], acc);
+    }
+    if (bf) {
+        acc = tv_wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) bf[r] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    }
+}
+
+// block = 64 columns x 4 row lanes; every block walks all R rows of its columns
+__global__ __launch_bounds__(256) void fold_bwd_kernel(const float* __restrict__ dWf, const float* __restrict__ dbf, const float* __restrict__ W,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dW,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int Cc) {
+    __shared__ float s_g[4][64], s_b[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float ag = 0.f, ab = 0.f;
+    if (c < Cc) {
+        const float ga = gamma[c], be = beta ? beta[c] : 0.f;
+        for (int r = ry; r < R; r += 4) {
+            const float g = dWf[(size_t)r * Cc + c], w = W[(size_t)r * Cc + c];
+            const float gb = dbf ? dbf[r] : 0.f;
+            dW[(size_t)r * Cc + c] = fmaf(g, ga, gb * be);
+            ag = fmaf(g, w, ag);
+            ab = fmaf(gb, w, ab);
+        }
+    }
+    s_g[ry][cx] = ag;
+    s_b[ry][cx] = ab;
+    __syncthreads();
+    if (ry == 0 && c < Cc) {
+        dgamma[c] = (s_g[0][cx] + s_g[1][cx]) + (s_g[2][cx] + s_g[3][cx]);
+        if (dbeta) dbeta[c] = (s_b[0][cx] + s_b[1][cx]) + (s_b[2][cx] + s_b[3][cx]);
+    }
+}
+
+}  // namespace
+
+extern "C" int tv_fold_cols(const float* W, const float* gamma, const float* beta, float* Wf, float* bf, int R, int C, void* stream) {
+    TV_CHECK_ARG(W && gamma && Wf && R > 0 && C > 0 && (bf == nullptr) == (beta == nullptr), "tv_fold_cols: bad arguments");
+    hipLaunchKernelGGL(fold_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, W, gamma, beta, Wf, bf, R, C);
+    TV_CHECK_LAUNCH("tv_fold_cols");
+    return TV_OK;
+}
+
+extern "C" int tv_fold_cols_bwd(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,
+                                float* dgamma, float* dbeta, int R, int C, void* stream) {
+    TV_CHECK_ARG(dWf && W && gamma && dW && dgamma && R > 0 && C > 0, "tv_fold_cols_bwd: bad arguments");
+    TV_CHECK_ARG((beta == nullptr) == (dbeta == nullptr) && (beta == nullptr || dbf != nullptr), "tv_fold_cols_bwd: beta / dbeta / dbf must come together");
+    hipLaunchKernelGGL(fold_bwd_kernel, dim3(tv_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, dWf, dbf, W, gamma, beta, dW, dgamma, dbeta, R, C);
+    TV_CHECK_LAUNCH("tv_fold_cols_bwd");
+    return TV_OK;
+}

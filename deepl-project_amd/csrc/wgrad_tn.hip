@@ -34,6 +34,7 @@ struct WgradArgs {
     int kh, kw, stride, pad, up_shift, dil_mask;
     int tiles_ci, chunk_px, hw_shift, w_shift, plain;
     int xcd_order, base, ny;   // block order: see the kernel
+    int accum;                 // 1: add into dw / dbias even when one block owns the tile (in-place gradient accumulation)
     unsigned x_bytes;   // FAST path: extent of x in bytes
 };
 
@@ -419,12 +420,14 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
             for (int j = 0; j < NF; ++j) {
                 const int ci = ci0 + wn * WTX + j * 16 + (lane & 15);
                 if (ci < p.c_in) {
-                    if (p.plain) rowp[ci] = acc[i][j][r];   // one pixel chunk: this block owns the tile
+                    if (p.plain && !p.accum) rowp[ci] = acc[i][j][r];   // one pixel chunk: this block owns the tile
+                    else if (p.plain) rowp[ci] += acc[i][j][r];         // ... and adds to what an earlier micro-batch left there
                     else atomicAdd(rowp + ci, acc[i][j][r]);
                 }
             }
             if (bias_mine(i) && (lane & 15) == 0) {
-                if (p.plain) p.dbias[co] = accb[i][r];
+                if (p.plain && !p.accum) p.dbias[co] = accb[i][r];
+                else if (p.plain) p.dbias[co] += accb[i][r];
                 else atomicAdd(p.dbias + co, accb[i][r]);
             }
         }
@@ -669,7 +672,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn3_kernel(const WgradArgs p) {
                 for (int j = 0; j < NF; ++j) {
                     const int ci = ci0 + wn * WTX + j * 16 + (lane & 15);
                     if (ci < p.c_in) {
-                        if (p.plain) rowp[ci] = acc[t][i][j][r];
+                        if (p.plain && !p.accum) rowp[ci] = acc[t][i][j][r];
+                        else if (p.plain) rowp[ci] += acc[t][i][j][r];
                         else atomicAdd(rowp + ci, acc[t][i][j][r]);
                     }
                 }
@@ -685,7 +689,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn3_kernel(const WgradArgs p) {
                 v += __shfl_xor(v, 32, 64);
                 const int co = co0 + wm * WTG + i * 16 + (lane & 15);
                 if (lane < 16 && co < p.c_out) {
-                    if (p.plain) p.dbias[co] = v;
+                    if (p.plain && !p.accum) p.dbias[co] = v;
+                    else if (p.plain) p.dbias[co] += v;
                     else atomicAdd(p.dbias + co, v);
                 }
             }
@@ -883,7 +888,7 @@ extern "C" int tv_set_wgrad_config(int bkp, int waves, int blocks) {
 }
 
 // plan_only: no launch, returns 1 if the call would overwrite dw / dbias (single pixel chunk), 0 if it accumulates
-static int wgrad_impl(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias, void* stream, bool plan_only) {
+static int wgrad_impl(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias, void* stream, bool plan_only, int accum = 0) {
     TV_CHECK_ARG(d && (plan_only || (x && gy && dw)), "tv_wgrad_tn: null pointer");
     TV_CHECK_ARG(d->c_in > 0 && d->c_in % 8 == 0, "tv_wgrad_tn: c_in=%d must be a multiple of 8", d->c_in);
     TV_CHECK_ARG(d->c_out > 0 && d->c_out % 8 == 0, "tv_wgrad_tn: c_out=%d must be a multiple of 8", d->c_out);
@@ -909,6 +914,7 @@ static int wgrad_impl(const tv_conv_desc* d, const void* x, const void* gy, floa
     a.up_shift = d->up_shift; a.dil_mask = d->dil_mask;
     a.tiles_ci = 1; a.chunk_px = 0; a.hw_shift = -1; a.w_shift = -1; a.plain = 0; a.x_bytes = 0;
     a.xcd_order = 0; a.base = 1; a.ny = 1;
+    a.accum = accum;
     hipStream_t s = (hipStream_t)stream;
     {   // 3x3 / stride-1 / pad-1 on a power-of-two grid with both tensors below 2 GiB: the kx-triple kernel
         auto log2_exact = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return ((1 << sh) == v) ? sh : -1; };
@@ -970,6 +976,10 @@ static int wgrad_impl(const tv_conv_desc* d, const void* x, const void* gy, floa
 extern "C" int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias,
                            void* stream) {
     return wgrad_impl(d, x, gy, dw, dbias, stream, false);
+}
+
+extern "C" int tv_wgrad_tn_acc(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias, void* stream) {
+    return wgrad_impl(d, x, gy, dw, dbias, stream, false, 1);
 }
 
 extern "C" int tv_wgrad_tn_overwrites(const tv_conv_desc* d) {

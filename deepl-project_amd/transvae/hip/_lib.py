@@ -43,6 +43,7 @@ SIGNATURES = {
     "tv_igemm_nt_actgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P, _P]),
     "tv_wgrad_tn": (_I, [_DP, _P, _P, _P, _P, _P]),
     "tv_wgrad_tn_overwrites": (_I, [_DP]),
+    "tv_wgrad_tn_acc": (_I, [_DP, _P, _P, _P, _P, _P]),
     "tv_pack_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "tv_gn_partial_count": (_LL, [_I, _I, _I]),
     "tv_gn_stats": (_I, [_P, _P, _P, _I, _I, _I, _P]),
@@ -61,6 +62,8 @@ SIGNATURES = {
     "tv_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "tv_im2col3x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "tv_pool2x2_sum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "tv_fold_cols": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "tv_fold_cols_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "tv_vae_loss_partial_count": (_LL, [_LL, _LL]),
     "tv_vae_loss_l1_kl": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _LL, _F, _F, _F, _I, _F, _F, _P]),
     "tv_opt_chunk_elems": (_I, []),

@@ -95,6 +95,63 @@ def _c(t):
     return t.contiguous() if t is not None else None
 
 
+# ------------------------------------------------------------------------------------------------
+# parameter folds: norm affine in front of a Linear -> one projection (two launches instead of ~40 small PyTorch kernels)
+# ------------------------------------------------------------------------------------------------
+class FoldFn(torch.autograd.Function):
+    """(Wf, bf) for a list of (W [R, C], gamma [C], beta [C] | None) triples stacked along the rows:
+    Wf = cat_s(W_s * gamma_s),  bf = cat_s(W_s @ beta_s)  (bf is None when no triple has a beta)."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        Ws, gs, bs = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        ops._need_gpu(*Ws)
+        lib = L.load()
+        R, Cc = Ws[0].shape
+        has_b = bs[0] is not None
+        Wf = torch.empty((n * R, Cc), dtype=torch.float32, device=Ws[0].device)
+        bf = torch.empty((n * R,), dtype=torch.float32, device=Ws[0].device) if has_b else None
+        Ws = [w.contiguous() for w in Ws]
+        gs = [g.contiguous() for g in gs]
+        bs = [b.contiguous() if b is not None else None for b in bs]
+        for s in range(n):
+            ops._require(Ws[s].dtype == torch.float32 and tuple(Ws[s].shape) == (R, Cc) and gs[s].numel() == Cc, "fold: fp32 [R, C] weights")
+            L.check(lib.tv_fold_cols(_p(Ws[s]), _p(gs[s]), _p(bs[s]), _p(Wf[s * R:]), _p(bf[s * R:]) if has_b else None, R, Cc, _stream()),
+                    "tv_fold_cols")
+        ctx.n, ctx.has_b = n, has_b
+        ctx.save_for_backward(*Ws, *gs, *[b for b in bs if b is not None])
+        return (Wf, bf) if has_b else (Wf, None)
+
+    @staticmethod
+    def backward(ctx, dWf, dbf):
+        n, has_b = ctx.n, ctx.has_b
+        saved = ctx.saved_tensors
+        Ws, gs = saved[:n], saved[n:2 * n]
+        bs = saved[2 * n:] if has_b else [None] * n
+        lib = L.load()
+        R, Cc = Ws[0].shape
+        dWf = dWf.contiguous()
+        if has_b:
+            dbf = dbf.contiguous() if dbf is not None else torch.zeros((n * R,), dtype=torch.float32, device=dWf.device)
+        outW, outg, outb = [], [], []
+        for s in range(n):
+            dW = torch.empty_like(Ws[s])
+            dg = torch.empty_like(gs[s])
+            db = torch.empty_like(bs[s]) if has_b else None
+            L.check(lib.tv_fold_cols_bwd(_p(dWf[s * R:]), _p(dbf[s * R:]) if has_b else None, _p(Ws[s]), _p(gs[s]), _p(bs[s]), _p(dW), _p(dg),
+                                         _p(db), R, Cc, _stream()), "tv_fold_cols_bwd")
+            outW.append(dW)
+            outg.append(dg)
+            outb.append(db)
+        return (None, *outW, *outg, *outb)
+
+
+def fold(weights, gammas, betas=None):
+    n = len(weights)
+    betas = list(betas) if betas is not None else [None] * n
+    return FoldFn.apply(n, *weights, *gammas, *betas)
+
+
 import os
 
 # Weight gradients do not feed the data-gradient chain, so they CAN run on a side stream (TV_WGRAD_SIDE_STREAM=1) to
@@ -113,11 +170,22 @@ def _side_stream(device):
     return st
 
 
+def _stash(ctx, *pairs):
+    """pairs of (input index, tensor): remember which nn.Parameter each weight / bias input is, for in-place accumulation"""
+    ctx.gparams = {i: ops.param_of(t) for i, t in pairs}
+
+
 def _wg(ctx, iw, ib, geo, w, x, gz):
     """weight / bias gradient of one layer, skipped when neither input of the Function needs it (frozen parameters)."""
     need_w, need_b = ctx.needs_input_grad[iw], ctx.needs_input_grad[ib]
     if not (need_w or need_b):
         return None, None
+    if need_w and geo.mode not in ("shuf", "c3up"):
+        gp = getattr(ctx, "gparams", None)
+        views = ops.grad_views(gp.get(iw), w, gp.get(ib), need_b) if gp else None
+        if views is not None:      # micro-batch >= 2 of a step: add straight into param.grad, nothing for autograd to do
+            ops.wgrad_acc(geo.fwd_desc(0), x, gz, views[0], views[1])
+            return None, None
     if _SIDE["on"] and geo.mode not in ("shuf", "c3up"):
         out = ops.conv_wgrad_alloc(geo, w, need_b)
         main = torch.cuda.current_stream()
@@ -154,6 +222,7 @@ class ResBlockFn(torch.autograd.Function):
         a2, mr2 = gn_silu_fwd(h1, g2, b2, 32, eps2)
         out, _, geo2, w2c = conv_forward(a2, w2, c2b, x, "c3s1", NONE, False)
         ctx.geo = (geo1, geo2)
+        _stash(ctx, (3, w1), (4, c1b), (7, w2), (8, c2b))
         ctx.recompute = bool(recompute)
         if recompute:
             ctx.save_for_backward(x, h1, mr1, mr2, g1, b1, g2, b2, w1c, w2c)
@@ -206,6 +275,7 @@ class AttnBranchFn(torch.autograd.Function):
         L.check(lib.tv_attn_fwd(_p(qkv), _p(o), _p(lse), B, N, heads, scale, _stream()), "tv_attn_fwd")
         out, _, geo_p, wpc = conv_forward(o, wp, _c(bp), t, "linear", NONE, False)
         ctx.geo = (geo_q, geo_p)
+        _stash(ctx, (2, wqkv), (3, bqkv), (4, wp), (5, bp))
         ctx.meta = (B, N, heads, scale, eps_rms, eps_ln)
         ctx.save_for_backward(t, w_rms, xh, qkv, o, lse, wq, wpc, tab)
         return out
@@ -248,6 +318,7 @@ class ConvFFNBranchFn(torch.autograd.Function):
         u2, _, geo3, w3c = conv_forward(c2.view(T, mid), w3, _c(b3), u, "linear", NONE, False)
         out, _, geo_out, w_out_c = conv_forward(u2, w_out, _c(b_out), t, "linear", NONE, False)
         ctx.geo = (geo_in, geo1, geo2, geo3, geo_out)
+        _stash(ctx, (1, w_in), (2, b_in), (3, w1), (4, b1), (5, w2), (6, b2), (7, w3), (8, b3), (9, w_out), (10, b_out))
         ctx.meta = (B, H, W, eps_rms)
         ctx.save_for_backward(t, r, u, pre_u, c1, pre_c1, c2, pre_c2, u2, w_in_c, w1c, w2c, w3c, w_out_c)
         return out
@@ -291,6 +362,7 @@ class DownsampleFn(torch.autograd.Function):
         h, pre_h, g0, w0c = conv_forward(x, w0, _c(b0), None, "c3s1", SILU, any(ctx.needs_input_grad) and _WANT)
         out, _, g2, w2c = conv_forward(h, w2, _c(b2), dc, "c3s2", NONE, False)
         ctx.geo = (g0, g2, gdc)
+        _stash(ctx, (1, w0), (2, b0), (3, w2), (4, b2), (5, wdc), (6, bdc))
         ctx.save_for_backward(x, h, pre_h, w0c, w2c, wdcc)
         return out
 
@@ -321,6 +393,7 @@ class UpsampleFn(torch.autograd.Function):
         h, pre_h, g1, w1c = conv_forward(x, w1, _c(b1), None, "c3up", SILU, any(ctx.needs_input_grad) and _WANT)
         out, _, g3, w3c = conv_forward(h, w3, _c(b3), dc, "c3s1", NONE, False)
         ctx.geo = (g1, g3, gdc)
+        _stash(ctx, (1, w1), (2, b1), (3, w3), (4, b3), (5, wdc), (6, bdc))
         ctx.save_for_backward(x, h, pre_h, w1c, w3c, wdcc)
         return out
 

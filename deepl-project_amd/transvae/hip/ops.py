@@ -231,6 +231,54 @@ def wgrad(desc: L.ConvDesc, x, gy, dw, dbias):
     L.check(lib.tv_wgrad_tn(C.byref(desc), _p(x), _p(gy), _p(dw), _p(dbias), _stream()), "tv_wgrad_tn")
 
 
+def wgrad_acc(desc: L.ConvDesc, x, gy, dw, dbias):
+    """dw += ..., dbias += ...  (the buffers hold the gradients of earlier micro-batches)"""
+    L.check(L.load().tv_wgrad_tn_acc(C.byref(desc), _p(x), _p(gy), _p(dw), _p(dbias), _stream()), "tv_wgrad_tn_acc")
+
+
+# In-place gradient accumulation across the micro-batches of one optimizer step (transvae.parallel.train_step switches it on
+# for every micro-batch after the first, and never for one whose backward must fire DDP's reduction hooks): the block
+# Functions then add their weight / bias gradients straight into `param.grad` and hand autograd nothing to accumulate.
+_accum_grads = False
+
+
+@contextlib.contextmanager
+def accumulate_grads_in_place(on: bool = True):
+    global _accum_grads
+    prev, _accum_grads = _accum_grads, bool(on)
+    try:
+        yield
+    finally:
+        _accum_grads = prev
+
+
+def param_of(t: Optional[torch.Tensor]):
+    """The nn.Parameter a weight / bias input is (a view of), or None (derived tensors: folds, pads, concatenations)."""
+    if t is None:
+        return None
+    base = t._base if t._base is not None else t
+    return base if isinstance(base, torch.nn.Parameter) else None
+
+
+def grad_views(pw, w: torch.Tensor, pb, need_b: bool):
+    """(dw buffer laid out like `w` inside pw.grad, bias gradient buffer | None) when both can be accumulated in place."""
+    if not _accum_grads or pw is None or pw.grad is None:
+        return None
+    gw = pw.grad
+    if gw.dtype != torch.float32 or gw.stride() != pw.stride() or w.numel() != pw.numel() or not w.is_contiguous():
+        return None
+    off = w.storage_offset() - pw.storage_offset()
+    if off < 0 or w.untyped_storage().data_ptr() != pw.untyped_storage().data_ptr():   # (a repacked copy, not a view)
+        return None
+    dw = gw.as_strided(tuple(w.shape), tuple(w.stride()), gw.storage_offset() + off)
+    db = None
+    if need_b:
+        if pb is None or pb.grad is None or pb.grad.dtype != torch.float32 or not pb.grad.is_contiguous():
+            return None
+        db = pb.grad
+    return dw, db
+
+
 _ones_cache = {}
 
 

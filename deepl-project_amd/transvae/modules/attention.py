@@ -97,8 +97,11 @@ class FlashAttentionWithRoPE(nn.Module):
 
     def folded_qkv(self):
         """[3C, C] weight and [3C] bias with the LayerNorm affines folded in (fp32, differentiable)."""
+        lins, lns = (self.to_q, self.to_k, self.to_v), (self.norm_q, self.norm_k, self.norm_v)
+        if self.to_q.weight.is_cuda:      # one launch per projection, forward and backward (fused.FoldFn)
+            return fused.fold([l.weight for l in lins], [n.weight for n in lns], [n.bias for n in lns])
         ws, bs = [], []
-        for lin, ln in ((self.to_q, self.norm_q), (self.to_k, self.norm_k), (self.to_v, self.norm_v)):
+        for lin, ln in zip(lins, lns):
             ws.append(lin.weight * ln.weight[None, :])
             bs.append(lin.weight @ ln.bias)
         return torch.cat(ws, 0), torch.cat(bs, 0)

@@ -48,7 +48,8 @@ class ConvFFN(nn.Module):
         """t: [B*H*W, d] bf16 residual stream.  Returns t + ffn(RMSNorm(t))."""
         hid, mid = self.hidden_dim, self.conv_hidden
         c0, c2, c4 = self.conv[0], self.conv[2], self.conv[4]
-        return fused.ConvFFNBranchFn.apply(t, self.proj_in.weight * rms_weight[None, :], self.proj_in.bias,
+        w_in = fused.fold([self.proj_in.weight], [rms_weight])[0]      # RMSNorm weight folded into proj_in (one launch)
+        return fused.ConvFFNBranchFn.apply(t, w_in, self.proj_in.bias,
                                            c0.weight.view(mid, hid), c0.bias, c2.weight.permute(0, 2, 3, 1), c2.bias,
                                            c4.weight.view(hid, mid), c4.bias, self.proj_out.weight, self.proj_out.bias,
                                            B, H, W, rms_eps)

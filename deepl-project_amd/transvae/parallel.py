@@ -76,6 +76,14 @@ def wrap_ddp(model: nn.Module, device: Optional[torch.device], bucket_mb: int = 
                                                find_unused_parameters=False)
 
 
+def _accumulate_in_place(x: torch.Tensor, on: bool):
+    """Micro-batches after the first add their weight gradients straight into param.grad (HIP path; see ops)."""
+    if x.is_cuda and on:
+        from .hip import ops
+        return ops.accumulate_grads_in_place(True)
+    return contextlib.nullcontext()
+
+
 def _packed_weight_cache(x: torch.Tensor):
     """The weights do not change between the micro-batches of a step: keep their bf16 repacks (HIP path only)."""
     if x.is_cuda:
@@ -163,7 +171,9 @@ def train_step(ddp_model: nn.Module, optimizer: torch.optim.Optimizer, x_local: 
         for i, (s, c) in enumerate(chunks):
             last = i == len(chunks) - 1
             sync_ctx = contextlib.nullcontext() if (last or not hasattr(ddp_model, "no_sync")) else ddp_model.no_sync()
-            with sync_ctx:
+            # in-place accumulation hands autograd no gradient for those parameters, so DDP's hooks would not fire: never on
+            # the micro-batch that synchronises
+            with sync_ctx, _accumulate_in_place(x_local, i > 0 and (world == 1 or not last)):
                 loss = forward_loss(ddp_model, x_local[s:s + c]) * (c * world / global_batch)
                 loss.backward()
             total += loss.detach()

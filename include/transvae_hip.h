@@ -120,6 +120,10 @@ int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const void* w, con
 int tv_wgrad_tn(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias,
                 void* stream);
 int tv_wgrad_tn_overwrites(const tv_conv_desc* d);
+/* tv_wgrad_tn that always ADDS into dw / dbias (they hold the sum of earlier micro-batches): gradient accumulation without
+ * autograd's separate add pass over 4.2 GB of gradients per micro-batch (R/train.py:557-646 accumulates through
+ * loss.backward() into .grad). */
+int tv_wgrad_tn_acc(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias, void* stream);
 
 /*
  * fp32 -> bf16 weight repack.  src: [O, T, I] fp32 (T = kh*kw taps).
@@ -231,6 +235,14 @@ typedef struct tv_pack_form {
     long long tile_start;
 } tv_pack_form;
 int tv_pack_weight_multi(const tv_pack_form* forms_dev, int n_forms, long long total_tiles, void* stream);
+
+/* Parameter folds ------------------------------------------------------------------------------------
+ * A LayerNorm / RMSNorm affine in front of a Linear folds into the projection (attention.py:39-48,71-78; blocks.py:146-149):
+ *   Wf[r][c] = W[r][c] * gamma[c],   bf[r] = sum_c W[r][c] * beta[c]     (beta / bf NULL together: no bias term)
+ * and the gradients back onto W, gamma, beta in one pass (fp32, [R, C] row-major; column sums in a fixed order). */
+int tv_fold_cols(const float* W, const float* gamma, const float* beta, float* Wf, float* bf, int R, int C, void* stream);
+int tv_fold_cols_bwd(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta,
+                     float* dW, float* dgamma, float* dbeta, int R, int C, void* stream);
 
 /* Closed-form loss terms on the path's outputs, value and gradient in one pass ---------------------
  *   out[0] = l1_weight * mean |f(recon) - target|     f = identity (R/transvae/losses/vae_loss.py:83-84) or sigmoid (P/...:80-84)

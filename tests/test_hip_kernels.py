@@ -462,6 +462,35 @@ def test_layout_and_im2col():
     assert torch.equal(col[..., :27], r16(pat)) and float(col[..., 27:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("R,Cc,n,bias", [(384, 384, 3, True), (1536, 384, 1, False), (100, 72, 3, True)])
+def test_parameter_fold_matches_autograd(R, Cc, n, bias):
+    """fused.fold (tv_fold_cols / tv_fold_cols_bwd): Wf = cat(W_s * gamma_s), bf = cat(W_s @ beta_s) and the gradients onto
+    W, gamma, beta -- against the PyTorch formulation it replaces (R/transvae/modules/attention.py:39-48,71-78)."""
+    from transvae.hip import fused
+    Ws = [gen(R, Cc, seed=10 + s).to(dev()).requires_grad_(True) for s in range(n)]
+    gs = [(1 + 0.1 * gen(Cc, seed=20 + s)).to(dev()).requires_grad_(True) for s in range(n)]
+    bs = [(0.1 * gen(Cc, seed=30 + s)).to(dev()).requires_grad_(True) for s in range(n)] if bias else None
+    Wf, bf = fused.fold(Ws, gs, bs)
+    ref_W = torch.cat([w * g[None, :] for w, g in zip(Ws, gs)], 0)
+    assert torch.allclose(Wf, ref_W, rtol=1e-6, atol=1e-7)
+    gW = gen(n * R, Cc, seed=40).to(dev())
+    loss = (Wf * gW).sum()
+    ref_loss = (ref_W * gW).sum()
+    if bias:
+        ref_b = torch.cat([w @ b for w, b in zip(Ws, bs)], 0)
+        assert torch.allclose(bf, ref_b, rtol=1e-4, atol=1e-5)
+        gb = gen(n * R, seed=41).to(dev())
+        loss = loss + (bf * gb).sum()
+        ref_loss = ref_loss + (ref_b * gb).sum()
+    else:
+        assert bf is None
+    leaves = Ws + gs + (bs or [])
+    got = torch.autograd.grad(loss, leaves)
+    ref = torch.autograd.grad(ref_loss, leaves)
+    for a, b in zip(got, ref):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), float((a - b).abs().max())
+
+
 def test_unsupported_shape_raises():
     from transvae.hip import ops
     x = torch.zeros(4, 40, dtype=BF, device=dev())       # c_in not a multiple of 32

@@ -110,6 +110,40 @@ def test_train_steps_follow_the_oracle(kind):
     assert agree / moved < 0.25 ** 2, (agree / moved) ** 0.5
 
 
+def test_in_place_gradient_accumulation_equals_autograd_accumulation():
+    """Micro-batches after the first add their weight / bias gradients straight into param.grad (tv_wgrad_tn_acc) instead of
+    returning them to autograd.  Three micro-batches with and without that mode give the same gradients (fp32 summation
+    order only), and the in-place mode really engaged (autograd saw no gradient for the convolution weights)."""
+    from transvae.hip import ops
+    from transvae.parallel import vae_bench_loss
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(3, 3, 64, 64, generator=g).to(DEV)
+    eps = torch.randn(3, 4, 4, 4, generator=g).to(DEV)
+    res = []
+    for in_place in (False, True):
+        m = micro_model(clamp_latent=True)
+        m.train()
+        for i in range(3):
+            with ops.accumulate_grads_in_place(in_place and i > 0):
+                recon, mu, logvar = m(x[i:i + 1], eps=eps[i:i + 1])
+                (vae_bench_loss(recon, x[i:i + 1], mu, logvar) / 3).backward()
+        res.append({k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    for k in res[0]:
+        a, b = res[0][k].double(), res[1][k].double()
+        assert float((a - b).norm()) <= 1e-5 * float(a.norm()) + 1e-9, k
+    # the mode engaged: with it on, a hook on a conv weight's AccumulateGrad does not fire for micro-batches 2 and 3
+    m = micro_model(clamp_latent=True)
+    m.train()
+    calls = []
+    w = m.encoder.stages[0][0].conv1.weight
+    w.register_post_accumulate_grad_hook(lambda p: calls.append(1))
+    for i in range(3):
+        with ops.accumulate_grads_in_place(i > 0):
+            recon, mu, logvar = m(x[i:i + 1], eps=eps[i:i + 1])
+            (vae_bench_loss(recon, x[i:i + 1], mu, logvar) / 3).backward()
+    assert len(calls) == 1
+
+
 @pytest.mark.parametrize("kind", optimizer_kinds())
 def test_non_finite_step_is_skipped_on_the_device(kind):
     """R/train_2.py:328-338.  Without the P/ clamps a logvar of +1000 overflows exp(): loss and gradients are not finite;
