@@ -34,17 +34,20 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(const float* __restrict__
     }
 }
 
-// block = 64 columns x 4 row lanes; every block walks all R rows of its columns
+// block = 64 columns x 4 row lanes over a chunk of FOLD_ROWS rows; partial column sums per row chunk, added in chunk order by
+// fold_finalize_kernel (bit-reproducible; a [6144, 1536] projection is 24 x 24 blocks instead of 24 blocks walking 6144 rows)
+constexpr int FOLD_ROWS = 256;
 __global__ __launch_bounds__(256) void fold_bwd_kernel(const float* __restrict__ dWf, const float* __restrict__ dbf, const float* __restrict__ W,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dW,
-                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int Cc) {
+                                                       float* __restrict__ part, int R, int Cc) {
     __shared__ float s_g[4][64], s_b[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * FOLD_ROWS, r1 = min(R, r0 + FOLD_ROWS);
     float ag = 0.f, ab = 0.f;
     if (c < Cc) {
         const float ga = gamma[c], be = beta ? beta[c] : 0.f;
-        for (int r = ry; r < R; r += 4) {
+        for (int r = r0 + ry; r < r1; r += 4) {
             const float g = dWf[(size_t)r * Cc + c], w = W[(size_t)r * Cc + c];
             const float gb = dbf ? dbf[r] : 0.f;
             dW[(size_t)r * Cc + c] = fmaf(g, ga, gb * be);
@@ -56,9 +59,23 @@ __global__ __launch_bounds__(256) void fold_bwd_kernel(const float* __restrict__
     s_b[ry][cx] = ab;
     __syncthreads();
     if (ry == 0 && c < Cc) {
-        dgamma[c] = (s_g[0][cx] + s_g[1][cx]) + (s_g[2][cx] + s_g[3][cx]);
-        if (dbeta) dbeta[c] = (s_b[0][cx] + s_b[1][cx]) + (s_b[2][cx] + s_b[3][cx]);
+        float* pr = part + (size_t)blockIdx.y * 2 * Cc;
+        pr[c] = (s_g[0][cx] + s_g[1][cx]) + (s_g[2][cx] + s_g[3][cx]);
+        pr[Cc + c] = (s_b[0][cx] + s_b[1][cx]) + (s_b[2][cx] + s_b[3][cx]);
     }
+}
+
+__global__ __launch_bounds__(256) void fold_finalize_kernel(const float* __restrict__ part, int nchunk, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int Cc) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Cc) return;
+    float g = 0.f, b = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+        g += part[(size_t)k * 2 * Cc + c];
+        b += part[(size_t)k * 2 * Cc + Cc + c];
+    }
+    dgamma[c] = g;
+    if (dbeta) dbeta[c] = b;
 }
 
 }  // namespace
@@ -70,11 +87,15 @@ extern "C" int tv_fold_cols(const float* W, const float* gamma, const float* bet
     return TV_OK;
 }
 
+extern "C" long long tv_fold_partial_count(int R, int C) { return (long long)tv_cdiv(R, FOLD_ROWS) * 2 * C; }
+
 extern "C" int tv_fold_cols_bwd(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta, float* dW,
-                                float* dgamma, float* dbeta, int R, int C, void* stream) {
-    TV_CHECK_ARG(dWf && W && gamma && dW && dgamma && R > 0 && C > 0, "tv_fold_cols_bwd: bad arguments");
+                                float* dgamma, float* dbeta, float* partials, int R, int C, void* stream) {
+    TV_CHECK_ARG(dWf && W && gamma && dW && dgamma && partials && R > 0 && C > 0, "tv_fold_cols_bwd: bad arguments");
     TV_CHECK_ARG((beta == nullptr) == (dbeta == nullptr) && (beta == nullptr || dbf != nullptr), "tv_fold_cols_bwd: beta / dbeta / dbf must come together");
-    hipLaunchKernelGGL(fold_bwd_kernel, dim3(tv_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, dWf, dbf, W, gamma, beta, dW, dgamma, dbeta, R, C);
+    const int nchunk = tv_cdiv(R, FOLD_ROWS);
+    hipLaunchKernelGGL(fold_bwd_kernel, dim3(tv_cdiv(C, 64), nchunk), dim3(256), 0, (hipStream_t)stream, dWf, dbf, W, gamma, beta, dW, partials, R, C);
+    hipLaunchKernelGGL(fold_finalize_kernel, dim3(tv_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)partials, nchunk, dgamma, dbeta, C);
     TV_CHECK_LAUNCH("tv_fold_cols_bwd");
     return TV_OK;
 }

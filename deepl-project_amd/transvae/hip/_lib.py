@@ -63,7 +63,8 @@ SIGNATURES = {
     "tv_im2col3x3": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "tv_pool2x2_sum": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "tv_fold_cols": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
-    "tv_fold_cols_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "tv_fold_partial_count": (_LL, [_I, _I]),
+    "tv_fold_cols_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "tv_vae_loss_partial_count": (_LL, [_LL, _LL]),
     "tv_vae_loss_l1_kl": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _LL, _F, _F, _F, _I, _F, _F, _P]),
     "tv_opt_chunk_elems": (_I, []),

@@ -134,12 +134,13 @@ class FoldFn(torch.autograd.Function):
         if has_b:
             dbf = dbf.contiguous() if dbf is not None else torch.zeros((n * R,), dtype=torch.float32, device=dWf.device)
         outW, outg, outb = [], [], []
+        part = torch.empty((lib.tv_fold_partial_count(R, Cc),), dtype=torch.float32, device=dWf.device)
         for s in range(n):
             dW = torch.empty_like(Ws[s])
             dg = torch.empty_like(gs[s])
             db = torch.empty_like(bs[s]) if has_b else None
             L.check(lib.tv_fold_cols_bwd(_p(dWf[s * R:]), _p(dbf[s * R:]) if has_b else None, _p(Ws[s]), _p(gs[s]), _p(bs[s]), _p(dW), _p(dg),
-                                         _p(db), R, Cc, _stream()), "tv_fold_cols_bwd")
+                                         _p(db), _p(part), R, Cc, _stream()), "tv_fold_cols_bwd")
             outW.append(dW)
             outg.append(dg)
             outb.append(db)

@@ -262,21 +262,31 @@ def param_of(t: Optional[torch.Tensor]):
 
 def grad_views(pw, w: torch.Tensor, pb, need_b: bool):
     """(dw buffer laid out like `w` inside pw.grad, bias gradient buffer | None) when both can be accumulated in place."""
-    if not _accum_grads or pw is None or pw.grad is None:
+    if not _accum_grads:
         return None
-    gw = pw.grad
-    if gw.dtype != torch.float32 or gw.stride() != pw.stride() or w.numel() != pw.numel() or not w.is_contiguous():
-        return None
-    off = w.storage_offset() - pw.storage_offset()
-    if off < 0 or w.untyped_storage().data_ptr() != pw.untyped_storage().data_ptr():   # (a repacked copy, not a view)
+    why = None
+    if pw is None or pw.grad is None:
+        why = "no parameter / no gradient yet"
+    else:
+        gw = pw.grad
+        off = w.storage_offset() - pw.storage_offset()
+        if gw.dtype != torch.float32 or gw.stride() != pw.stride():
+            why = f"grad layout {gw.dtype} {gw.stride()} vs {pw.stride()}"
+        elif w.numel() != pw.numel() or not w.is_contiguous() or off < 0:
+            why = "weight view does not cover the parameter"
+        elif w.untyped_storage().data_ptr() != pw.untyped_storage().data_ptr():
+            why = "weight is a repacked copy, not a view"
+        elif need_b and (pb is None or pb.grad is None or pb.grad.dtype != torch.float32 or not pb.grad.is_contiguous()):
+            why = "bias gradient not available in place"
+    if why is not None:
+        if _ACC_DEBUG:
+            print("[transvae.hip] in-place accumulation skipped:", why, tuple(w.shape), flush=True)
         return None
     dw = gw.as_strided(tuple(w.shape), tuple(w.stride()), gw.storage_offset() + off)
-    db = None
-    if need_b:
-        if pb is None or pb.grad is None or pb.grad.dtype != torch.float32 or not pb.grad.is_contiguous():
-            return None
-        db = pb.grad
-    return dw, db
+    return dw, (pb.grad if need_b else None)
+
+
+_ACC_DEBUG = __import__("os").environ.get("TV_DEBUG_ACC") == "1"
 
 
 _ones_cache = {}

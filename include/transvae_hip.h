@@ -241,8 +241,9 @@ int tv_pack_weight_multi(const tv_pack_form* forms_dev, int n_forms, long long t
  *   Wf[r][c] = W[r][c] * gamma[c],   bf[r] = sum_c W[r][c] * beta[c]     (beta / bf NULL together: no bias term)
  * and the gradients back onto W, gamma, beta in one pass (fp32, [R, C] row-major; column sums in a fixed order). */
 int tv_fold_cols(const float* W, const float* gamma, const float* beta, float* Wf, float* bf, int R, int C, void* stream);
+long long tv_fold_partial_count(int R, int C);     /* floats of scratch for tv_fold_cols_bwd */
 int tv_fold_cols_bwd(const float* dWf, const float* dbf, const float* W, const float* gamma, const float* beta,
-                     float* dW, float* dgamma, float* dbeta, int R, int C, void* stream);
+                     float* dW, float* dgamma, float* dbeta, float* partials, int R, int C, void* stream);
 
 /* Closed-form loss terms on the path's outputs, value and gradient in one pass ---------------------
  *   out[0] = l1_weight * mean |f(recon) - target|     f = identity (R/transvae/losses/vae_loss.py:83-84) or sigmoid (P/...:80-84)
