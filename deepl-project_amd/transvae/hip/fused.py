@@ -186,7 +186,9 @@ def _wg(ctx, iw, ib, geo, w, x, gz):
         views = ops.grad_views(gp.get(iw), w, gp.get(ib), need_b) if gp else None
         if views is not None:      # micro-batch >= 2 of a step: add straight into param.grad, nothing for autograd to do
             ops.wgrad_acc(geo.fwd_desc(0), x, gz, views[0], views[1])
+            ops.acc_stats["in_place"] += 1
             return None, None
+        ops.acc_stats["autograd"] += 1
     if _SIDE["on"] and geo.mode not in ("shuf", "c3up"):
         out = ops.conv_wgrad_alloc(geo, w, need_b)
         main = torch.cuda.current_stream()

@@ -240,6 +240,7 @@ def wgrad_acc(desc: L.ConvDesc, x, gy, dw, dbias):
 # for every micro-batch after the first, and never for one whose backward must fire DDP's reduction hooks): the block
 # Functions then add their weight / bias gradients straight into `param.grad` and hand autograd nothing to accumulate.
 _accum_grads = False
+acc_stats = {"in_place": 0, "autograd": 0}     # weight gradients added in place / handed to autograd (diagnostics, tests)
 
 
 @contextlib.contextmanager
