@@ -89,12 +89,16 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def _pointer_table(self, ps, with_grad: bool):
         rows = []
+        self._relaid = []
         for p in ps:
             st = self._state_of(p) if with_grad else None
             g = p.grad if with_grad else None
             if with_grad:
-                if g.dtype != torch.float32 or g.stride() != p.stride() or g.device != p.device:
-                    raise RuntimeError("FusedAdamW: gradient must be fp32 with the parameter's memory layout")
+                if g.dtype != torch.float32 or g.device != p.device:
+                    raise RuntimeError("FusedAdamW: gradients must be fp32 on the parameter's device")
+                if g.stride() != p.stride():      # (autograd and DDP's bucket views follow the parameter's layout; anything else: re-lay once)
+                    g = torch.empty_like(p).copy_(g)
+                    self._relaid.append(g)
             sh = self._shadow.get(id(p))
             rows.append((p.data_ptr(), g.data_ptr() if with_grad else 0, st["exp_avg"].data_ptr() if with_grad else 0,
                          st["exp_avg_sq"].data_ptr() if with_grad else 0, sh.data_ptr() if sh is not None else 0, p.numel()))
