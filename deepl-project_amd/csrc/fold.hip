@@ -14,54 +14,89 @@
 
 namespace {
 
+// forward: one block per 4 rows, float4 along the columns (C % 4 == 0 on this path; scalar tail kernel otherwise)
 __global__ __launch_bounds__(256) void fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ Wf, float* __restrict__ bf, int R, int Cc) {
-    __shared__ float s_red[4];
-    const int r = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;          // one wave per row
+    if (r >= R) return;
     const float* w = W + (size_t)r * Cc;
     float* o = Wf + (size_t)r * Cc;
     float acc = 0.f;
-    for (int c = threadIdx.x; c < Cc; c += 256) {
-        const float v = w[c];
-        o[c] = v * gamma[c];
-        if (beta) acc = fmaf(v, beta[c], acc);
+    if ((Cc & 3) == 0) {
+        const int n4 = Cc >> 2;
+        for (int c4 = lane; c4 < n4; c4 += 64) {
+            const f32x4 v = *(const f32x4*)(w + c4 * 4), g = *(const f32x4*)(gamma + c4 * 4);
+            *(f32x4*)(o + c4 * 4) = v * g;
+            if (beta) {
+                const f32x4 b = *(const f32x4*)(beta + c4 * 4);
+                acc += v[0] * b[0] + v[1] * b[1] + v[2] * b[2] + v[3] * b[3];
+            }
+        }
+    } else {
+        for (int c = lane; c < Cc; c += 64) {
+            const float v = w[c];
+            o[c] = v * gamma[c];
+            if (beta) acc = fmaf(v, beta[c], acc);
+        }
     }
     if (bf) {
         acc = tv_wave_sum(acc);
-        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) bf[r] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        if (lane == 0) bf[r] = acc;
     }
 }
 
-// block = 64 columns x 4 row lanes over a chunk of FOLD_ROWS rows; partial column sums per row chunk, added in chunk order by
-// fold_finalize_kernel (bit-reproducible; a [6144, 1536] projection is 24 x 24 blocks instead of 24 blocks walking 6144 rows)
-constexpr int FOLD_ROWS = 256;
+// backward: block = 64 columns (16 threads x float4) x 16 row lanes over a chunk of FOLD_ROWS rows; partial column sums per
+// row chunk, added in chunk order by fold_finalize_kernel (bit-reproducible; a [6144, 1536] projection is 24 x 96 blocks)
+constexpr int FOLD_ROWS = 64;
 __global__ __launch_bounds__(256) void fold_bwd_kernel(const float* __restrict__ dWf, const float* __restrict__ dbf, const float* __restrict__ W,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dW,
                                                        float* __restrict__ part, int R, int Cc) {
-    __shared__ float s_g[4][64], s_b[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ float s_g[16][64], s_b[16][64];
+    const int cg = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cg * 4;
     const int r0 = blockIdx.y * FOLD_ROWS, r1 = min(R, r0 + FOLD_ROWS);
-    float ag = 0.f, ab = 0.f;
-    if (c < Cc) {
-        const float ga = gamma[c], be = beta ? beta[c] : 0.f;
-        for (int r = r0 + ry; r < r1; r += 4) {
-            const float g = dWf[(size_t)r * Cc + c], w = W[(size_t)r * Cc + c];
+    f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (Cc & 3) == 0 && c + 3 < Cc;
+    if (vec) {
+        const f32x4 ga = *(const f32x4*)(gamma + c);
+        const f32x4 be = beta ? *(const f32x4*)(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = r0 + ry; r < r1; r += 16) {
+            const f32x4 g = *(const f32x4*)(dWf + (size_t)r * Cc + c), w = *(const f32x4*)(W + (size_t)r * Cc + c);
             const float gb = dbf ? dbf[r] : 0.f;
-            dW[(size_t)r * Cc + c] = fmaf(g, ga, gb * be);
-            ag = fmaf(g, w, ag);
-            ab = fmaf(gb, w, ab);
+            *(f32x4*)(dW + (size_t)r * Cc + c) = g * ga + be * gb;
+            ag += g * w;
+            ab += w * gb;
+        }
+    } else {
+        for (int e = 0; e < 4; ++e) {
+            if (c + e >= Cc) break;
+            const float ga = gamma[c + e], be = beta ? beta[c + e] : 0.f;
+            for (int r = r0 + ry; r < r1; r += 16) {
+                const float g = dWf[(size_t)r * Cc + c + e], w = W[(size_t)r * Cc + c + e];
+                const float gb = dbf ? dbf[r] : 0.f;
+                dW[(size_t)r * Cc + c + e] = fmaf(g, ga, gb * be);
+                ag[e] = fmaf(g, w, ag[e]);
+                ab[e] = fmaf(gb, w, ab[e]);
+            }
         }
     }
-    s_g[ry][cx] = ag;
-    s_b[ry][cx] = ab;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s_g[ry][cg * 4 + e] = ag[e];
+        s_b[ry][cg * 4 + e] = ab[e];
+    }
     __syncthreads();
-    if (ry == 0 && c < Cc) {
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < Cc) {
+        float g = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {        // fixed order
+            g += s_g[k][threadIdx.x];
+            b += s_b[k][threadIdx.x];
+        }
         float* pr = part + (size_t)blockIdx.y * 2 * Cc;
-        pr[c] = (s_g[0][cx] + s_g[1][cx]) + (s_g[2][cx] + s_g[3][cx]);
-        pr[Cc + c] = (s_b[0][cx] + s_b[1][cx]) + (s_b[2][cx] + s_b[3][cx]);
+        pr[blockIdx.x * 64 + threadIdx.x] = g;
+        pr[Cc + blockIdx.x * 64 + threadIdx.x] = b;
     }
 }
 
@@ -82,7 +117,7 @@ __global__ __launch_bounds__(256) void fold_finalize_kernel(const float* __restr
 
 extern "C" int tv_fold_cols(const float* W, const float* gamma, const float* beta, float* Wf, float* bf, int R, int C, void* stream) {
     TV_CHECK_ARG(W && gamma && Wf && R > 0 && C > 0 && (bf == nullptr) == (beta == nullptr), "tv_fold_cols: bad arguments");
-    hipLaunchKernelGGL(fold_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, W, gamma, beta, Wf, bf, R, C);
+    hipLaunchKernelGGL(fold_fwd_kernel, dim3(tv_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, W, gamma, beta, Wf, bf, R, C);
     TV_CHECK_LAUNCH("tv_fold_cols");
     return TV_OK;
 }
