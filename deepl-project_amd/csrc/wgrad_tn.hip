@@ -261,10 +261,8 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
     }
 
     f32x4 acc[MF][NF];
-    f32x4 accb[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
-        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -274,11 +272,25 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
     // Fragment f = wm*MF + i of this co tile is summed by the wave in slot f mod (taps*NWN), slot = tap + taps*wn, of the
     // blocks with ci tile 0: every tap's block carries its share (at most one extra MFMA per wave on the 3x3 layers).
     // (A single-branch form -- one owned fragment per wave, selected outside the fragment loop -- measured slower.)
-    const bool do_bias = (p.dbias != nullptr) && ci_tile == 0;
-    const int bias_slots = taps * NWN, bias_slot = tap + taps * wn;
-    auto bias_mine = [&](int i) { return do_bias && ((wm * MF + i) % bias_slots) == bias_slot; };
-    const bf16 one = (bf16)1.0f;
-    const bf16x8 ones = {one, one, one, one, one, one, one, one};
+    // (round 2: the extra MFMA per owned fragment sat behind a scalar branch per fragment in every wave's MFMA stream; the
+    //  owners now add the gy fragments up with vector ALU work -- lane L of an A fragment holds 8 pixels of output channel
+    //  L & 15 -- behind ONE wave-uniform branch per sub-step.  Owners: the blocks of (tap 0, ci tile 0); fragment i of a
+    //  wave row belongs to the wave with wn == i % NWN.)
+    const bool do_bias = (p.dbias != nullptr) && ci_tile == 0 && tap == 0;
+    float bsum[(MF + NWN - 1) / NWN];
+#pragma unroll
+    for (int k = 0; k < (MF + NWN - 1) / NWN; ++k) bsum[k] = 0.f;
+    auto bias_add = [&](const bf16x4 (&alo)[MF], const bf16x4 (&ahi)[MF]) {
+        if (!do_bias) return;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+            if (i % NWN == wn) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a += (float)alo[i][e] + (float)ahi[i][e];
+                bsum[i / NWN] += a;
+            }
+    };
 
     const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     auto join = [](bf16x4 lo, bf16x4 hi) { return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
@@ -313,9 +325,7 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
 #pragma unroll
                 for (int j = 0; j < H; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], join(blo[j], bhi[j]), acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-                if (bias_mine(i)) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+            bias_add(alo, ahi);
             lds_wait_all();
 #pragma unroll
             for (int i = 0; i < MF; ++i)
@@ -357,8 +367,8 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
 #pragma unroll
                 for (int j = 0; j < NF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, join(blo[j], bhi[j]), acc[i][j], 0, 0, 0);
-                if (bias_mine(i)) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ones, accb[i], 0, 0, 0);
             }
+            bias_add(alo, ahi);
         };
         const int U = nsteps * KH;
         // sub-step u: wait for its fragments, start the reads of u+1 (after the stage hand-over if u+1 opens a stage), multiply
@@ -425,12 +435,22 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
                     else atomicAdd(rowp + ci, acc[i][j][r]);
                 }
             }
-            if (bias_mine(i) && (lane & 15) == 0) {
-                if (p.plain && !p.accum) p.dbias[co] = accb[i][r];
-                else if (p.plain) p.dbias[co] += accb[i][r];
-                else atomicAdd(p.dbias + co, accb[i][r]);
-            }
         }
+    }
+    if (do_bias) {   // lanes L, L+16, L+32, L+48 hold partial sums of the same output channel
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+            if (i % NWN == wn) {
+                float v = bsum[i / NWN];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int co = co0 + wm * WTG + i * 16 + (lane & 15);
+                if (lane < 16 && co < p.c_out) {
+                    if (p.plain && !p.accum) p.dbias[co] = v;
+                    else if (p.plain) p.dbias[co] += v;
+                    else atomicAdd(p.dbias + co, v);
+                }
+            }
     }
 }
 
