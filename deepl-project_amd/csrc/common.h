@@ -62,11 +62,14 @@ struct TvPerDeviceOnce {
 #define TV_ACT_SAVE_DERIV 16  // (flag on desc.act) pre_act receives act'(pre-activation) instead of the pre-activation
 
 __device__ __forceinline__ float tv_fast_exp(float x) { return __expf(x); }
+// v_rcp_f32 (1 ulp).  `__frcp_rn` compiles to the IEEE-correct division sequence (v_div_scale x2, v_rcp, 4 FMAs, v_div_fmas,
+// v_div_fixup: ten instructions) -- it was a third of the GELU / SiLU epilogue arithmetic, which runs with the matrix pipe idle.
+__device__ __forceinline__ float tv_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // erf(x) with e = exp(-x^2) handed back (the Gaussian the GELU gradient needs as well)
 __device__ __forceinline__ float tv_erf_e(float x, float& e) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = tv_fast_rcp(fmaf(0.3275911f, ax, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
@@ -91,7 +94,7 @@ __device__ __forceinline__ float tv_gelu_grad(float z) {
     return fmaf(z * 0.3989422804014327f, e, cdf);
 }
 
-__device__ __forceinline__ float tv_sigmoid(float z) { return __frcp_rn(1.0f + tv_fast_exp(-z)); }
+__device__ __forceinline__ float tv_sigmoid(float z) { return tv_fast_rcp(1.0f + tv_fast_exp(-z)); }
 __device__ __forceinline__ float tv_silu(float z) { return z * tv_sigmoid(z); }
 __device__ __forceinline__ float tv_silu_grad(float z) {
     const float s = tv_sigmoid(z);

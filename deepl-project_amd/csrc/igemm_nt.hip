@@ -87,6 +87,9 @@ struct IgemmArgs {
 #ifndef TV_PP_DMA_FIRST
 #define TV_PP_DMA_FIRST 0  // ping-pong: DMA pieces of a load phase before (1) or after (0) its fragment reads; 2 = threaded between them
 #endif
+#ifndef TV_GENERIC_DPHASE
+#define TV_GENERIC_DPHASE 1   // generic pipelined loop: DMA slots staggered by wave through a run-time phase (scalar branches in the MFMA stream)
+#endif
 #ifndef TV_NO_PINGPONG
 #define TV_NO_PINGPONG 1   // ping-pong main loop of the 8-wave tiles: measured, not (yet) a win -- see DESIGN.md
 #endif
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
                 for (int j = 0; j < NF; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
                     const int idx = i * NF + j;   // DMA slots staggered by wave (see conv3x3_halo_kernel)
-                    if (ISSUE && idx / HGAP < NI && idx % HGAP == dphase) {
+                    if (ISSUE && idx / HGAP < NI && (TV_GENERIC_DPHASE ? idx % HGAP == dphase : idx % HGAP == HGAP - 1)) {
                         __builtin_amdgcn_sched_barrier(0);
                         issue_piece(nbase, idx / HGAP);
                         __builtin_amdgcn_sched_barrier(0);
