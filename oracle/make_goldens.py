@@ -278,6 +278,9 @@ def large():
         lcfg = yaml.safe_load(f)["model"]
     model = R["TransVAE"](config=lcfg, variant="large", compression_ratio=16, latent_dim=32)
     load_filled(model, "")
+    with torch.no_grad():      # a log-variance head of standard deviation ~1 (oracle/filler.py: LARGE_GAINS)
+        for k, g in filler.LARGE_GAINS.items():
+            dict(model.named_parameters())[k].mul_(g)
     x = filler.rand_input("large.x", (1, 3, 256, 256))
     eps = filler.randn_input("large.eps", (1, 32, 16, 16))
     orig = torch.randn_like

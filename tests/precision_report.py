@@ -47,7 +47,7 @@ def build(name):
     else:
         cfg, L, shape = O.variant_config(name, 16, 32), 32, (1, 3, 256, 256)
         m = TransVAE(variant=name, latent_dim=L)
-    sd = filler.fill_state_dict(O.state_dict_schema(cfg, L))
+    sd = filler.fill_state_dict(O.state_dict_schema(cfg, L), gains=filler.LARGE_GAINS if name == "large" else None)
     m.load_state_dict(sd)
     return m.cuda().eval(), sd, cfg, L, shape
 

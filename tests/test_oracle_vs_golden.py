@@ -204,7 +204,7 @@ def test_oracle_large_forward_matches_reference_golden(golden_dir):
     test_large_one_image_forward_backward_against_oracle_and_reference_golden."""
     g = dict(np.load(os.path.join(golden_dir, "large_one_image.npz")))
     cfg = O.variant_config("large", 16, 32)
-    sd = filler.fill_state_dict(O.state_dict_schema(cfg, 32))
+    sd = filler.fill_state_dict(O.state_dict_schema(cfg, 32), gains=filler.LARGE_GAINS)
     x = filler.rand_input("large.x", (1, 3, 256, 256))
     eps = filler.randn_input("large.eps", (1, 32, 16, 16))
     with torch.no_grad():
