@@ -432,7 +432,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 
     // running state of the "next K-step to stage"
     const int cch = p.c_in / BK;  // channel chunks per tap
+#ifdef TV_ABL_K1   // (ablation, tools/probes/k1_probe.py: one K-step per tile = launch + prologue + epilogue)
+    const int nk = 1;
+#else
     const int nk = p.kh * p.kw * cch;
+#endif
     int st_ky = 0, st_kx = 0, st_ch = 0, st_t = 0;
     const bf16* a_src[A_IT];
     bool a_ok[A_IT];
@@ -794,6 +798,16 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
     // ---- epilogue ---------------------------------------------------------------------------------
     if (TV_SETPRIO) __builtin_amdgcn_s_setprio(0);
     TV_T(5);
+#ifdef TV_ABL_NO_EPI   // (ablation: main loop only)
+    {
+        float chk = 0.f;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) chk += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (chk != 123.456f) return;   // (keeps the accumulators live; practically always taken)
+    }
+#endif
     f32x4 bvals[NF];
     load_bias<WTN>(p, lane, n0 + wn * WTN, bvals);
     __syncthreads();                           // every wave is done reading the stage buffers

@@ -132,6 +132,9 @@ def rope_apply(t: Tensor, tabs) -> Tensor:
     return torch.stack([o1, o2], dim=-1).flatten(-2)
 
 
+SCORE_BYTES_MAX = 16 << 30   # above this the attention scores are formed 2048 query rows at a time (same arithmetic per row)
+
+
 def attention_tokens(t: Tensor, H: int, W: int, sd: SD, p: str, head_dim: int = 64,
                      use_rope: bool = True) -> Tensor:
     """FlashAttentionWithRoPE on token-major input t=[B,N,C] (the block's
@@ -155,8 +158,13 @@ def attention_tokens(t: Tensor, H: int, W: int, sd: SD, p: str, head_dim: int = 
         tabs = rope_tables(H, W, sd[p + "rope.inv_freq"])
         q = rope_apply(q, tabs)
         k = rope_apply(k, tabs)
-    s = (q @ k.transpose(-1, -2)) * (head_dim ** -0.5)
-    o = torch.softmax(s, dim=-1) @ v
+    scale = head_dim ** -0.5
+    if B * h * N * N * 4 <= SCORE_BYTES_MAX:
+        s = (q @ k.transpose(-1, -2)) * scale
+        o = torch.softmax(s, dim=-1) @ v
+    else:   # (N = 65 536 at 1024 x 1024: 100 GB of scores -- query rows are independent, so take them 2048 at a time)
+        kt = k.transpose(-1, -2)
+        o = torch.cat([torch.softmax((q[:, :, i:i + 2048] @ kt) * scale, dim=-1) @ v for i in range(0, N, 2048)], dim=2)
     o = o.transpose(1, 2).reshape(B, N, C)
     return F.linear(o, sd[p + "proj.weight"], sd[p + "proj.bias"])
 

@@ -547,6 +547,30 @@ def test_stage2_block_at_512px_tokens_16384_against_oracle():
     assert worst[0] < TOL_GRAD, worst
 
 
+def test_stage2_block_at_1024px_tokens_65536_forward_against_oracle():
+    """SURVEY 8f-3's largest shape (multi-resolution evaluation, R/scripts/reproduce/test_rope_extrapolation.py:28-51 pushed to
+    1024 x 1024): the stage-2 TransVAE block of Large on a 256 x 256 token grid -- N = 65 536, 6 heads, 512 key tiles per
+    query tile, RoPE tables 4x beyond the training grid -- forward (the no-grad inference path) against the fp32 oracle
+    block, whose score matrix is taken 2048 query rows at a time."""
+    from transvae.modules.blocks import TransVAEBlock
+    blk = TransVAEBlock(dim=384)
+    sd = {k: filler.fill_tensor("b1024." + k, v.shape) for k, v in blk.state_dict().items()}
+    blk.load_state_dict(sd)
+    blk = blk.to(DEV).eval()
+    x = filler.randn_input("b1024.x", (1, 384, 256, 256))
+    with torch.no_grad():
+        y = blk(x.to(DEV))
+        y2 = blk(x.to(DEV))
+    assert torch.equal(y, y2)                      # deterministic
+    assert torch.isfinite(y).all()
+    torch.set_num_threads(min(16, os.cpu_count()))
+    with torch.no_grad():
+        yr = O.transvae_block(x, {"b." + k: v for k, v in sd.items()}, "b.")
+    e = l2rel(y, yr)
+    print("N=65536 block forward rel-L2 vs oracle:", e)
+    assert e < TOL_OUT, e
+
+
 def test_large_512_one_image_forward_against_oracle():
     """BASELINE config 4's correctness leg: TransVAE-Large f16d32 on ONE 512 x 512 image (token grids 128^2 / 64^2 / 32^2,
     10.5 TFLOP forward) against the fp32 oracle; same bf16-tier bounds as the 256 x 256 test."""

@@ -215,3 +215,21 @@ def test_oracle_large_forward_matches_reference_golden(golden_dir):
         got = t.flatten().double()[g[f"{nm}.idx"]].numpy()
         assert np.linalg.norm(got - g[f"{nm}.val"]) < 1e-4 * np.linalg.norm(g[f"{nm}.val"]), nm
         assert abs(float(t.double().norm()) - float(g[f"{nm}.l2"])) < 1e-5 * float(g[f"{nm}.l2"]), nm
+
+
+def test_oracle_attention_row_chunking_is_the_same_arithmetic():
+    """The oracle forms the N = 65 536 score matrix 2048 query rows at a time (tests/test_model_gpu.py, 1024 x 1024 block);
+    forced on a small case the chunked form must reproduce the plain one."""
+    blk_sd = {k: filler.fill_tensor("chunk." + k, shp) for k, shp in O.state_dict_schema(O.MICRO, latent_dim=4).items()
+              if k.startswith("encoder.stages.2.0.")}
+    pre = "encoder.stages.2.0."
+    C = blk_sd[pre + "norm1.weight"].shape[0]
+    x = filler.randn_input("chunk.x", (1, C, 64, 48))          # N = 3072 > 2048: two chunks, the second ragged
+    y_plain = O.transvae_block(x, blk_sd, pre)
+    old = O.SCORE_BYTES_MAX
+    try:
+        O.SCORE_BYTES_MAX = 0
+        y_chunk = O.transvae_block(x, blk_sd, pre)
+    finally:
+        O.SCORE_BYTES_MAX = old
+    assert torch.allclose(y_plain, y_chunk, rtol=0, atol=2e-6 * float(y_plain.abs().max()))
