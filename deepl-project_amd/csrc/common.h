@@ -117,6 +117,22 @@ __device__ __forceinline__ float tv_act_grad_rt(int act, float z) {
     if (act == TV_ACT_SILU) return tv_silu_grad(z);
     return 1.0f;
 }
+template <int ACT>
+__device__ __forceinline__ float tv_act_with_grad(float z, float& g) {
+    if constexpr (ACT == TV_ACT_GELU) {
+        float e;
+        const float cdf = fmaf(0.5f, tv_erf_e(z * 0.70710678118654752f, e), 0.5f);
+        g = fmaf(z * 0.3989422804014327f, e, cdf);
+        return z * cdf;
+    } else if constexpr (ACT == TV_ACT_SILU) {
+        const float s = tv_sigmoid(z);
+        g = s * fmaf(z, 1.0f - s, 1.0f);
+        return z * s;
+    } else {
+        g = 1.0f;
+        return z;
+    }
+}
 // act(z) with its derivative from the same erf / exponential / sigmoid (forward epilogue that saves the derivative)
 __device__ __forceinline__ float tv_act_with_grad_rt(int act, float z, float& g) {
     if (act == TV_ACT_GELU) {

@@ -45,6 +45,7 @@ struct IgemmArgs {
     int act;
     int aux_act;
     int pre_deriv;     // pre receives act'(pre-activation) (TV_ACT_SAVE_DERIV)
+    int form;          // register-epilogue form of an EPI 0 launch (EF_*), 0 = generic LDS loop
     const float* rope; // QKV projection: RoPE table [tokens][4][32] applied to output columns < rope_cols (q and k thirds)
     int rope_tokens, rope_cols;
     int hw_shift, w_shift;  // log2 of h_out*w_out / w_out when both are powers of two, else -1
@@ -94,6 +95,15 @@ struct IgemmArgs {
 #define TV_NO_PINGPONG 1   // ping-pong main loop of the 8-wave tiles: measured, not (yet) a win -- see DESIGN.md
 #endif
 
+// Order of the output channels inside a wave's WTN-wide weight slab.  The MFMA is issued as D' = W_frag x A_frag^T: lane
+// (fq, fi) ends up with 4 channels (operand rows 4 fq .. 4 fq + 3) of pixel fi per fragment.  Fragments come in pairs
+// (2c, 2c+1) over a 32-channel block c; operand row r of fragment j is local channel  (j/2)*32 + (r/4)*8 + (j%2)*4 + r%4,
+// so a lane's pair is 8 CONSECUTIVE channels (one 16-byte bf16 chunk) and the four lanes of a pixel cover the block's 64
+// contiguous bytes: the epilogue stores straight from the registers (epilogue_direct).
+__device__ __forceinline__ constexpr int bfrag_off(int j) { return (j >> 1) * 32 + (j & 1) * 4; }   // fragment j, operand row 0
+__device__ __forceinline__ int bfrag_lane_row(int fi) { return (fi >> 2) * 8 + (fi & 3); }           // operand row fi of fragment 0
+__device__ __forceinline__ int bfrag_reader(int rl) { return (((rl & 31) >> 3) << 2) | (rl & 3); }    // operand row that reads local channel rl
+
 // f(integral_constant<int, I>) for I = I0 .. N-1: an unrolled loop whose index is usable as a template argument
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -140,6 +150,10 @@ __device__ __forceinline__ int swz_of(int i) {  // i: row index inside a 16-row 
 // every output is rounded to bf16 exactly once (a bf16 park rounded the pre-activation first: +20-40 % rel-L2 error on
 // whole-model outputs, tests/precision_report.py).
 // m_of_row(r) = output pixel index (b, oy, ox linearised) of wave-tile row r; the caller has synchronised the block.
+#ifndef TV_EPI_LDS
+#define TV_EPI_LDS 0   // 1: the round-1 epilogue (tile parked in LDS as fp32, streamed out row by row), kept for A/B timing
+#endif
+
 template <int WTM, int WTN>
 constexpr int epilogue_lds_bytes(int nwaves) {
     return nwaves * (WTM >= 32 ? WTM / 2 : WTM) * (WTN * 4 + 16);
@@ -163,14 +177,228 @@ __device__ __forceinline__ void load_bias(const IgemmArgs& p, int lane, int nw0,
     const int fq = lane >> 4;
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
-        const int n = nw0 + fq * (4 * NF) + j * 4;
+        const int n = nw0 + bfrag_off(j) + fq * 8;
         bv[j] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
+// Register-layout epilogues.  A lane's accumulators of fragment row i are, per 32-channel block c, 8 CONSECUTIVE output
+// channels of ONE pixel (bfrag_off): 16 bytes of bf16, and the common epilogues are elementwise on those chunks -- bias,
+// activation (+ saved derivative), residual add, saved-derivative multiply -- so their arithmetic needs no row-major
+// view.  Memory accesses do: the finished bf16 chunks (and the loaded residual / saved chunks, the other way) go through
+// a cross-lane transposition (epi_to_lines / epi_from_lines) so that every load and store instruction covers 8 whole
+// 128-byte lines with consecutive lanes on consecutive addresses.  A block without a line partner (WTN = 96: one of
+// three) moves as 64-byte halves.
+// Measured (tools/probes/k1_probe.py, K = 384 -> N = 1536, 24 tiles per CU): the LDS epilogue below (tile parked as fp32,
+// streamed out by a row loop) costs 6.5-7.7 us per 256x256 tile, 6.1 us of it without any global store, against 5.2 us of
+// MFMA time.  The register form is fully unrolled (accumulator indices must be static), so it exists only as COMPACT
+// compile-time forms, one per common (activation, residual) combination: a single body with run-time flags unrolls to
+// ~20 000 instructions, runs out of the instruction cache and is 20-35 % SLOWER than the LDS loop, which therefore stays
+// as the generic form (RoPE, shuffled stores, saved pre-activations, ...).  Same-box A/B of the plain form against the
+// LDS loop: K = 384 layers 1.22x, the dominant 3x3 convolution 1.07x forward / 1.10x data gradient (2.21 -> 2.01 ms =
+// 1385 TFLOP/s); results bit-identical (same fp32 arithmetic, one rounding).
+enum { EF_GENERIC = 0, EF_PLAIN = 1, EF_GELU_D = 2, EF_SILU_D = 3, EF_GELU = 4, EF_SILU = 5, EF_RES = 6, EF_DERIV = 7 };
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void epi_pair_exchange(bf16x8& a, bf16x8& b) {   // an involution: lanes fi < 8 keep a, lanes fi >= 8 keep b
+    const u32x4 x = __builtin_bit_cast(u32x4, a), y = __builtin_bit_cast(u32x4, b);
+    u32x4 s, t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s[e] = __builtin_amdgcn_update_dpp(x[e], y[e], 0x128 /* row_ror:8 */, 0xF, 0xC, false);
+        t[e] = __builtin_amdgcn_update_dpp(y[e], x[e], 0x128, 0xF, 0x3, false);
+    }
+    a = __builtin_bit_cast(bf16x8, s);
+    b = __builtin_bit_cast(bf16x8, t);
+}
+// register layout <-> line layout.  Register layout: lane (fq, fi) holds blocks C0 (a) and C0+1 (b) of pixel fi, 16 bytes
+// each at byte fq*16 of the block.  Line layout: lane l holds bytes (l & 7) * 16 of the 128-byte line of pixel l >> 3 (a)
+// and of pixel 8 + (l >> 3) (b) -- consecutive lanes are consecutive addresses, which is what the memory pipeline
+// coalesces (it merges neighbouring lanes only: with the 16-byte pieces of a line on lanes 8 or 16 apart the stores ran
+// 30-40 % slower than through LDS).  Two steps: the fi ^ 8 exchange, then one ds_bpermute per dword (the LDS crossbar, no
+// LDS memory).  `idx` = epi_line_index(lane).
+__device__ __forceinline__ int epi_line_index(int lane) { return (((lane & 3) << 4) + (lane >> 3) + (((lane >> 2) & 1) << 3)) << 2; }
+__device__ __forceinline__ void epi_to_lines(bf16x8& a, bf16x8& b, int idx) {
+    epi_pair_exchange(a, b);
+    u32x4 x = __builtin_bit_cast(u32x4, a), y = __builtin_bit_cast(u32x4, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        x[e] = __builtin_amdgcn_ds_bpermute(idx, x[e]);
+        y[e] = __builtin_amdgcn_ds_bpermute(idx, y[e]);
+    }
+    a = __builtin_bit_cast(bf16x8, x);
+    b = __builtin_bit_cast(bf16x8, y);
+}
+__device__ __forceinline__ void epi_from_lines(bf16x8& a, bf16x8& b, int idx) {
+    u32x4 x = __builtin_bit_cast(u32x4, a), y = __builtin_bit_cast(u32x4, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        x[e] = __builtin_amdgcn_ds_permute(idx, x[e]);
+        y[e] = __builtin_amdgcn_ds_permute(idx, y[e]);
+    }
+    a = __builtin_bit_cast(bf16x8, x);
+    b = __builtin_bit_cast(bf16x8, y);
+    epi_pair_exchange(a, b);
+}
+// one block alone: lane l holds bytes (l & 3) * 16 of the 64-byte half line of pixel l >> 2
+__device__ __forceinline__ int epi_half_index(int lane) { return (((lane & 3) << 4) + (lane >> 2)) << 2; }
+__device__ __forceinline__ void epi_to_half(bf16x8& a, int idx) {
+    u32x4 x = __builtin_bit_cast(u32x4, a);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_ds_bpermute(idx, x[e]);
+    a = __builtin_bit_cast(bf16x8, x);
+}
+__device__ __forceinline__ void epi_from_half(bf16x8& a, int idx) {
+    u32x4 x = __builtin_bit_cast(u32x4, a);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = __builtin_amdgcn_ds_permute(idx, x[e]);
+    a = __builtin_bit_cast(bf16x8, x);
+}
+
+// the elementwise part on one 8-channel chunk (v: accumulator + bias, fp32): the output chunk; `zd` the saved derivative.
+// `ld`: the residual (EF_RES) or the saved derivative (EF_DERIV) of the same elements.
+template <int FORM>
+__device__ __forceinline__ bf16x8 epi_math(float (&v)[8], const bf16x8& ld, bf16x8& zd) {
+    if constexpr (FORM == EF_RES) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)ld[e];
+    } else if constexpr (FORM == EF_DERIV) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= (float)ld[e];
+    } else if constexpr (FORM == EF_GELU_D || FORM == EF_SILU_D) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float g;
+            v[e] = tv_act_with_grad<FORM == EF_GELU_D ? TV_ACT_GELU : TV_ACT_SILU>(v[e], g);
+            zd[e] = (bf16)g;
+        }
+    } else if constexpr (FORM == EF_GELU || FORM == EF_SILU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tv_act<FORM == EF_GELU ? TV_ACT_GELU : TV_ACT_SILU>(v[e]);
+    }
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (bf16)v[e];
+    return z;
+}
+
+template <int WTM, int WTN, int FORM, class RowMap>
+__device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 (&acc)[WTM / 16][WTN / 16], const f32x4 (&bv)[WTN / 16],
+                                                int lane, int nw0, RowMap m_of_row) {
+    constexpr int MF = WTM / 16, NF = WTN / 16, NC = NF / 2;
+    static_assert(NF % 2 == 0, "a lane's channels must come in whole 8-channel chunks");
+    constexpr bool LOADS = FORM == EF_RES || FORM == EF_DERIV;
+    constexpr bool SAVES = FORM == EF_GELU_D || FORM == EF_SILU_D;
+    // fragment rows per batch: the loads of a whole batch are issued before its arithmetic (their latency runs once per
+    // batch, not once per line; one load per line in flight measured 0.96-0.99x of the LDS form, which batches them)
+    constexpr int IB = !LOADS ? 1 : (MF % 4 == 0 ? 4 : (MF % 2 == 0 ? 2 : 1));
+    const int fq = lane >> 4;
+    const bf16* __restrict__ lsrc = FORM == EF_DERIV ? p.aux : p.res;
+    const int lidx = epi_line_index(lane), hidx = epi_half_index(lane);
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto chunk_values = [&](int i, int c, float (&v)[8]) {
+        const f32x4 lo = acc[i][2 * c] + bv[2 * c], hi = acc[i][2 * c + 1] + bv[2 * c + 1];
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    };
+    // which blocks pair up into lines depends on where the wave's slab starts inside a 128-byte line (wave-uniform)
+    auto run = [&](auto odd_c) {
+        constexpr bool ODD = decltype(odd_c)::value;     // slab starts in the second half of a line
+        constexpr int P0 = ODD ? 1 : 0, NP = (NC - P0) / 2;
+        constexpr int S0 = ODD ? 0 : NC - 1;             // the block without a partner, if any
+        constexpr bool SINGLE = P0 + 2 * NP < NC || ODD;
+        static_for<0, MF / IB>([&](auto b_c) {
+            constexpr int i0 = decltype(b_c)::value * IB;
+            size_t o1[IB][NP > 0 ? NP : 1], o2[IB][NP > 0 ? NP : 1], os[IB];
+            bool k1[IB][NP > 0 ? NP : 1], k2[IB][NP > 0 ? NP : 1], ks[IB];
+            [[maybe_unused]] bf16x8 la[IB][NP > 0 ? NP : 1], lb[IB][NP > 0 ? NP : 1], ls[IB];
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) {
+                const int r1 = (i0 + ii) * 16 + (lane >> 3);               // line layout: my pixel in the first / second access
+                const int m1 = m_of_row(r1), m2 = m_of_row(r1 + 8);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const int nx = nw0 + (P0 + 2 * u) * 32 + (lane & 7) * 8;   //          my channels
+                    k1[ii][u] = m1 < p.M && nx < p.N;
+                    k2[ii][u] = m2 < p.M && nx < p.N;
+                    o1[ii][u] = k1[ii][u] ? (size_t)m1 * p.ldo + nx : 0;
+                    o2[ii][u] = k2[ii][u] ? (size_t)m2 * p.ldo + nx : 0;
+                    if constexpr (LOADS) {
+                        la[ii][u] = k1[ii][u] ? *(const bf16x8*)(lsrc + o1[ii][u]) : zero8;
+                        lb[ii][u] = k2[ii][u] ? *(const bf16x8*)(lsrc + o2[ii][u]) : zero8;
+                    }
+                }
+                if constexpr (SINGLE) {
+                    const int ms = m_of_row((i0 + ii) * 16 + (lane >> 2));
+                    const int nx = nw0 + S0 * 32 + (lane & 3) * 8;
+                    ks[ii] = ms < p.M && nx < p.N;
+                    os[ii] = ks[ii] ? (size_t)ms * p.ldo + nx : 0;
+                    if constexpr (LOADS) ls[ii] = ks[ii] ? *(const bf16x8*)(lsrc + os[ii]) : zero8;
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < IB; ++ii) {
+                const int i = i0 + ii;
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const int C0 = P0 + 2 * u;
+                    bf16x8 ra = zero8, rb = zero8, da = zero8, db = zero8;
+                    if constexpr (LOADS) {
+                        ra = la[ii][u];
+                        rb = lb[ii][u];
+                        epi_from_lines(ra, rb, lidx);    // -> blocks C0 / C0+1 of MY pixel (register layout)
+                    }
+                    float va[8], vb[8];
+                    chunk_values(i, C0, va);
+                    chunk_values(i, C0 + 1, vb);
+                    bf16x8 za = epi_math<FORM>(va, ra, da);
+                    bf16x8 zb = epi_math<FORM>(vb, rb, db);
+                    if constexpr (SAVES) {
+                        epi_to_lines(da, db, lidx);
+                        if (k1[ii][u]) *(bf16x8*)(p.pre + o1[ii][u]) = da;
+                        if (k2[ii][u]) *(bf16x8*)(p.pre + o2[ii][u]) = db;
+                    }
+                    epi_to_lines(za, zb, lidx);
+#ifdef TV_ABL_NO_STORE
+                    if (za[0] == (bf16)123.0f)   // (keeps the values live; practically never true)
+#endif
+                    {
+                        if (k1[ii][u]) *(bf16x8*)(p.out + o1[ii][u]) = za;
+                        if (k2[ii][u]) *(bf16x8*)(p.out + o2[ii][u]) = zb;
+                    }
+                }
+                if constexpr (SINGLE) {
+                    bf16x8 r = zero8, d = zero8;
+                    if constexpr (LOADS) {
+                        r = ls[ii];
+                        epi_from_half(r, hidx);
+                    }
+                    float v[8];
+                    chunk_values(i, S0, v);
+                    bf16x8 z = epi_math<FORM>(v, r, d);
+                    if constexpr (SAVES) {
+                        epi_to_half(d, hidx);
+                        if (ks[ii]) *(bf16x8*)(p.pre + os[ii]) = d;
+                    }
+                    epi_to_half(z, hidx);
+#ifdef TV_ABL_NO_STORE
+                    if (z[0] == (bf16)123.0f)
+#endif
+                    if (ks[ii]) *(bf16x8*)(p.out + os[ii]) = z;
+                }
+            }
+        });
+    };
+    if constexpr (WTN % 64 == 0) {
+        run(std::false_type{});
+    } else {
+        if (nw0 & 32) run(std::true_type{});
+        else run(std::false_type{});
+    }
+}
+
 template <int WTM, int WTN, int EPI, class RowMap>
-__device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[WTM / 16][WTN / 16], const f32x4 (&bv)[WTN / 16], char* smem,
-                                         int wave, int lane, int nw0, RowMap m_of_row) {
+__device__ __forceinline__ void epilogue_lds(const IgemmArgs& p, const f32x4 (&acc)[WTM / 16][WTN / 16], const f32x4 (&bv)[WTN / 16], char* smem,
+                                             int wave, int lane, int nw0, RowMap m_of_row) {
     constexpr int MF = WTM / 16, NF = WTN / 16;
     constexpr int PASSES = MF >= 2 ? 2 : 1, MFP = MF / PASSES, RH = MFP * 16;   // rows per pass
     static_assert(MF % PASSES == 0, "wave tile rows");
@@ -206,7 +434,7 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
             const int i = ps * MFP + ii;
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
-                const int nl = fq * (4 * NF) + j * 4;
+                const int nl = bfrag_off(j) + fq * 8;
                 const f32x4 v = acc[i][j] + bv[j];
                 *(f32x4*)(ebuf + (ii * 16 + fi) * ERS + nl * 4) = v;
             }
@@ -324,6 +552,33 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
     }
 }
 
+// EPI (compile time) 1 / 2: the residual-add / derivative-multiply launches; EPI 0: p.form picks a compact register form
+// or the generic LDS loop.  The caller has NOT synchronised the block: only the LDS form needs every wave to be done with
+// the stage buffers (it parks the tile in them), the register forms let early waves start storing.
+template <int WTM, int WTN, int EPI, class RowMap>
+__device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[WTM / 16][WTN / 16], const f32x4 (&bv)[WTN / 16], char* smem,
+                                         int wave, int lane, int nw0, RowMap m_of_row) {
+    constexpr bool REG = !TV_EPI_LDS && (WTN / 16) % 2 == 0;
+    if constexpr (REG && EPI == 1) {
+        epilogue_direct<WTM, WTN, EF_RES>(p, acc, bv, lane, nw0, m_of_row);
+    } else if constexpr (REG && EPI == 2) {
+        epilogue_direct<WTM, WTN, EF_DERIV>(p, acc, bv, lane, nw0, m_of_row);
+    } else {
+        if constexpr (REG && EPI == 0) {
+            switch (p.form) {   // (wave-uniform)
+                case EF_PLAIN: epilogue_direct<WTM, WTN, EF_PLAIN>(p, acc, bv, lane, nw0, m_of_row); return;
+                case EF_GELU_D: epilogue_direct<WTM, WTN, EF_GELU_D>(p, acc, bv, lane, nw0, m_of_row); return;
+                case EF_SILU_D: epilogue_direct<WTM, WTN, EF_SILU_D>(p, acc, bv, lane, nw0, m_of_row); return;
+                case EF_GELU: epilogue_direct<WTM, WTN, EF_GELU>(p, acc, bv, lane, nw0, m_of_row); return;
+                case EF_SILU: epilogue_direct<WTM, WTN, EF_SILU>(p, acc, bv, lane, nw0, m_of_row); return;
+                default: break;
+            }
+        }
+        __syncthreads();                           // every wave is done reading the stage buffers
+        epilogue_lds<WTM, WTN, EPI>(p, acc, bv, smem, wave, lane, nw0, m_of_row);
+    }
+}
+
 // MODE 0: register-staged loads + ds_write (bring-up / debugging)
 // MODE 1: global_load_lds with 64-bit per-lane addresses (tensors >= 2 GiB)
 // MODE 2: buffer_load ... lds: SGPR descriptor + 32-bit per-lane offset fixed per tap + scalar K offset; padding
@@ -422,7 +677,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
         const int j = it * NW + wave;
         const int row = j * RPI + srow;
         const int rl = row % WTN;
-        const int fi = ((rl / (4 * NF)) << 2) | (row & 3);
+        const int fi = bfrag_reader(rl);
         const int c = (sslot ^ swz_of<BK>(fi)) * 8;
         const int n = n0 + row;
         b_ok[it] = (j < B_INSTR) && (n < p.N);
@@ -432,7 +687,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 
     // running state of the "next K-step to stage"
     const int cch = p.c_in / BK;  // channel chunks per tap
-#ifdef TV_ABL_K1   // (ablation, tools/probes/k1_probe.py: one K-step per tile = launch + prologue + epilogue)
+#ifdef TV_ABL_K1
     const int nk = 1;
 #else
     const int nk = p.kh * p.kw * cch;
@@ -541,7 +796,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
     const int fi = lane & 15, fq = lane >> 4;
     const int sw = swz_of<BK>(fi);
     const int a_row_off = (wm * WTM + fi) * (BK * 2);
-    const int b_row_off = A_BYTES + (wn * WTN + (fi >> 2) * (4 * NF) + (fi & 3)) * (BK * 2);
+    const int b_row_off = A_BYTES + (wn * WTN + bfrag_lane_row(fi)) * (BK * 2);
 
     f32x4 acc[MF][NF];
 #pragma unroll
@@ -570,7 +825,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 #else
                 for (int i = 0; i < MF; ++i) af[kk][i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
 #pragma unroll
-                for (int j = 0; j < NF; ++j) bfr[kk][j] = *(const bf16x8*)(sbase + b_row_off + j * 4 * (BK * 2) + coff);
+                for (int j = 0; j < NF; ++j) bfr[kk][j] = *(const bf16x8*)(sbase + b_row_off + bfrag_off(j) * (BK * 2) + coff);
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);   // keep every read ahead of the MFMAs (the scheduler would sink them again)
@@ -606,7 +861,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 #pragma unroll
                 for (int i = 0; i < MF; ++i) af[i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
 #pragma unroll
-                for (int j = 0; j < NF; ++j) bfr[j] = *(const bf16x8*)(sbase + b_row_off + j * 4 * (BK * 2) + coff);
+                for (int j = 0; j < NF; ++j) bfr[j] = *(const bf16x8*)(sbase + b_row_off + bfrag_off(j) * (BK * 2) + coff);
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
@@ -647,7 +902,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 #pragma unroll
             for (int i = 0; i < MF; ++i) fa[i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) fb[j] = *(const bf16x8*)(sbase + b_row_off + j * 4 * (BK * 2) + coff);
+            for (int j = 0; j < NF; ++j) fb[j] = *(const bf16x8*)(sbase + b_row_off + bfrag_off(j) * (BK * 2) + coff);
         };
         constexpr int HMF = MF * NF, HGAP = HMF / NI > 0 ? HMF / NI : 1;
         const int dphase = __builtin_amdgcn_readfirstlane(wave % HGAP);
@@ -727,7 +982,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 #pragma unroll
                 for (int i = 0; i < MF; ++i) af[kk][i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
 #pragma unroll
-                for (int j = 0; j < NF; ++j) bfr[kk][j] = *(const bf16x8*)(sbase + b_row_off + j * 4 * (BK * 2) + coff);
+                for (int j = 0; j < NF; ++j) bfr[kk][j] = *(const bf16x8*)(sbase + b_row_off + bfrag_off(j) * (BK * 2) + coff);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer may be refilled after the next barrier
             if (grp == 1) wait_vmcnt<0>();
@@ -798,7 +1053,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
     // ---- epilogue ---------------------------------------------------------------------------------
     if (TV_SETPRIO) __builtin_amdgcn_s_setprio(0);
     TV_T(5);
-#ifdef TV_ABL_NO_EPI   // (ablation: main loop only)
+#ifdef TV_ABL_NO_EPI
     {
         float chk = 0.f;
 #pragma unroll
@@ -810,7 +1065,6 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 #endif
     f32x4 bvals[NF];
     load_bias<WTN>(p, lane, n0 + wn * WTN, bvals);
-    __syncthreads();                           // every wave is done reading the stage buffers
     const int mrow0 = m0 + wm * WTM;
     epilogue<WTM, WTN, EPI>(p, acc, bvals, smem, wave, lane, n0 + wn * WTN, [&](int r) { return mrow0 + r; });
     TV_T(6);
@@ -896,7 +1150,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
         asm volatile("" : "+v"(l8));
         const int row = j * 8 + l8;
         const int rl = row % WTN;
-        const int fr = ((rl / (4 * NF)) << 2) | (row & 3);
+        const int fr = bfrag_reader(rl);
         const int c = ((lane & 7) ^ swz_of<BK>(fr)) * 8;
         const int n = n0 + row;
         return (n < p.N) ? (n * p.K + c) * 2 : OOB_OFFSET;
@@ -936,7 +1190,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
     const int fi = lane & 15, fq = lane >> 4;
     const int sw = swz_of<BK>(fi);
     const int hp_base = (wm * MF) * HWD + fi;     // halo pixel of (fragment 0, tap (0,0)); fragment i adds i*HWD, tap adds dy*HWD+dx
-    const int b_row_off = (wn * WTN + (fi >> 2) * (4 * NF) + (fi & 3)) * (BK * 2);
+    const int b_row_off = (wn * WTN + bfrag_lane_row(fi)) * (BK * 2);
 
     f32x4 acc[MF][NF];
 #pragma unroll
@@ -967,7 +1221,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                 for (int i = 0; i < MF; ++i) af[kk][i] = *(const bf16x8*)(abase + a_off[i] + (((kk * 4 + fq) ^ a_sw[i]) << 4));
                 const int coff = ((kk * 4 + fq) ^ sw) * 16;
 #pragma unroll
-                for (int j = 0; j < NF; ++j) bfr[kk][j] = *(const bf16x8*)(bbase + b_row_off + j * 4 * (BK * 2) + coff);
+                for (int j = 0; j < NF; ++j) bfr[kk][j] = *(const bf16x8*)(bbase + b_row_off + bfrag_off(j) * (BK * 2) + coff);
             }
             __builtin_amdgcn_sched_barrier(0);
             TV_T(3);
@@ -993,7 +1247,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                 for (int i = 0; i < MF; ++i) af[i] = *(const bf16x8*)(abase + a_off[i] + (((kk * 4 + fq) ^ a_sw[i]) << 4));
                 const int coff = ((kk * 4 + fq) ^ sw) * 16;
 #pragma unroll
-                for (int j = 0; j < NF; ++j) bfr[j] = *(const bf16x8*)(bbase + b_row_off + j * 4 * (BK * 2) + coff);
+                for (int j = 0; j < NF; ++j) bfr[j] = *(const bf16x8*)(bbase + b_row_off + bfrag_off(j) * (BK * 2) + coff);
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
@@ -1083,7 +1337,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
                     }
                     const int coff = ((kk * 4 + fq) ^ sw) * 16;
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) fb[kk][j] = *(const bf16x8*)(bslot + b_row_off + j * 4 * (BK * 2) + coff);
+                    for (int j = 0; j < NF; ++j) fb[kk][j] = *(const bf16x8*)(bslot + b_row_off + bfrag_off(j) * (BK * 2) + coff);
                     if constexpr (TV_PP_DMA_FIRST == 2) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (kk == 0) {
@@ -1186,7 +1440,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
             }
             const int coff = ((kk * 4 + fq) ^ sw) * 16;
 #pragma unroll
-            for (int j = 0; j < NF; ++j) fb[j] = *(const bf16x8*)(bbase + b_row_off + j * 4 * (BK * 2) + coff);
+            for (int j = 0; j < NF; ++j) fb[j] = *(const bf16x8*)(bbase + b_row_off + bfrag_off(j) * (BK * 2) + coff);
         };
         // One wave per SIMD (4-wave 256-row tile) has no partner to cover a block of fragment reads: there the reads of the
         // next half-step are threaded between the MFMAs as well (RD_THREAD), in the order the MFMAs will want them.
@@ -1198,7 +1452,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
 #endif
             if (k >= 1 && k <= NF) {
                 const int j = k - 1;
-                fb[j] = *(const bf16x8*)(bbase + b_row_off + j * 4 * (BK * 2) + ((kk * 4 + fq) ^ sw) * 16);
+                fb[j] = *(const bf16x8*)(bbase + b_row_off + bfrag_off(j) * (BK * 2) + ((kk * 4 + fq) ^ sw) * 16);
             } else {
                 const int i = k == 0 ? 0 : k - NF;
 #ifdef TV_ABL_CHEAP_ADDR
@@ -1370,7 +1624,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
     TV_T(5);
     f32x4 bvals[NF];
     load_bias<WTN>(p, lane, n0 + wn * WTN, bvals);
-    __syncthreads();
     // wave-tile row r -> output pixel: fragment row i = r / 16 is tile row wm*MF + i, r % 16 the column
     const int pix0 = (b * p.h_out + y0 + wm * MF) * p.w_out + x0;
     epilogue<WTM, WTN, EPI>(p, acc, bvals, smem, wave, lane, n0 + wn * WTN, [&](int r) { return pix0 + (r >> 4) * p.w_out + (r & 15); });
@@ -1399,6 +1652,16 @@ int epilogue_mode(const IgemmArgs& a) {
     if (!g_epi_modes || a.shuffle || a.pre || ((long long)a.M * a.ldo >> 3) >= 0xffffffffll) return 0;
     if (a.aux) return (a.aux_act == TV_ACT_DERIV && !a.res) ? 2 : 0;
     return (a.res && a.act == TV_ACT_NONE) ? 1 : 0;
+}
+
+// register form of an EPI 0 launch (see epilogue<>): the common elementwise combinations; everything else -> LDS loop
+int epilogue_form(const IgemmArgs& a) {
+    if (!g_epi_modes || a.rope || a.shuffle || a.aux || a.res) return EF_GENERIC;
+    if (a.pre) {
+        if (!a.pre_deriv) return EF_GENERIC;
+        return a.act == TV_ACT_GELU ? EF_GELU_D : (a.act == TV_ACT_SILU ? EF_SILU_D : EF_GENERIC);
+    }
+    return a.act == TV_ACT_NONE ? EF_PLAIN : (a.act == TV_ACT_GELU ? EF_GELU : (a.act == TV_ACT_SILU ? EF_SILU : EF_GENERIC));
 }
 
 template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE>
@@ -1690,6 +1953,7 @@ static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, co
     a.rope = rope.tab;
     a.rope_tokens = rope.tokens;
     a.rope_cols = rope.cols;
+    a.form = epilogue_form(a);
     {
         auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return ((1 << s) == v) ? s : -1; };
         a.w_shift = lg(d->w_out);
