@@ -349,6 +349,13 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
             const int stage = (u / KH) % STAGES, kk = u % KH;
             const unsigned sa = smem_addr + stage * STAGE + kk * 32 * (TG * 2);
             const unsigned sb = smem_addr + stage * STAGE + kk * 32 * (TX * 2);
+#ifdef TV_ABL_WG_NOLDS   // (ablation builds, tools/probes/build_variant.sh: the main loop without its transposing reads)
+#pragma unroll
+            for (int i = 0; i < MF; ++i) { alo[i] = bf16x4{1, 1, 1, 1}; ahi[i] = bf16x4{1, 1, 1, 1}; asm volatile("" : "+v"(alo[i]), "+v"(ahi[i])); }
+#pragma unroll
+            for (int j = 0; j < NF; ++j) { blo[j] = bf16x4{1, 1, 1, 1}; bhi[j] = bf16x4{1, 1, 1, 1}; asm volatile("" : "+v"(blo[j]), "+v"(bhi[j])); }
+            (void)sa; (void)sb;
+#else
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 alo[i] = lds_tr16(sa + a_off[0][i]);
@@ -359,14 +366,21 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
                 blo[j] = lds_tr16(sb + b_off[0][j]);
                 bhi[j] = lds_tr16(sb + b_off[1][j]);
             }
+#endif
         };
         auto mfma_sub = [&](const bf16x4 (&alo)[MF], const bf16x4 (&ahi)[MF], const bf16x4 (&blo)[NF], const bf16x4 (&bhi)[NF]) {
 #pragma unroll
             for (int i = 0; i < MF; ++i) {
                 const bf16x8 af = join(alo[i], ahi[i]);
 #pragma unroll
-                for (int j = 0; j < NF; ++j)
+                for (int j = 0; j < NF; ++j) {
+#ifdef TV_ABL_WG_NOMFMA
+                    const bf16x8 bfv = join(blo[j], bhi[j]);
+                    asm volatile("" ::"v"(af), "v"(bfv));
+#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, join(blo[j], bhi[j]), acc[i][j], 0, 0, 0);
+#endif
+                }
             }
             bias_add(alo, ahi);
         };
@@ -381,8 +395,14 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
                     // 2-deep ring waiting on the DMA for ~half of every wave's lifetime)
                     if (STAGES == 3 && s1 + 1 < nsteps) wait_vmcnt<G_IT + X_IT>();
                     else wait_vmcnt<0>();
+#ifndef TV_ABL_WG_NOBAR
                     __builtin_amdgcn_s_barrier();
+#endif
+#ifndef TV_ABL_WG_NODMA
+                    // (as one burst: threading the pieces between the MFMAs that follow, as the igemm kernels do, measured
+                    //  0.96x here -- tools/gemm_sweep.py, same box)
                     if (s1 + STAGES - 1 < nsteps) stage_issue(s1 + STAGES - 1, smem + ((s1 + STAGES - 1) % STAGES) * STAGE);
+#endif
                 }
                 read_sub(u + 1, nalo, nahi, nblo, nbhi);
             }
