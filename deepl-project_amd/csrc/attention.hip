@@ -318,10 +318,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p) {
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
-        if (v == 0) {
+        if (v == 0) {   // stored NEGATED, beside -lse log2(e): both enter the backward kernels as addends (see attn_bwd_dq_kernel)
             const long long bb = tok / p.N;
             const int n = (int)(tok - bb * p.N);
-            p.delta[((size_t)bb * p.heads + head) * p.N + n] = acc;
+            const size_t at = ((size_t)bb * p.heads + head) * p.N + n;
+            p.delta[at] = -acc;
+            p.delta[(size_t)p.B * p.heads * p.N + at] = -p.lse[at] * 1.4426950408889634f;
         }
     }
 }
@@ -357,13 +359,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         qf[st] = v;
         gf[st] = g;
     }
-    float lse = 0.f, delta = 0.f;
+    // P = exp2(S c2 + nl), dS = P (dP + nd) with nl = -lse log2(e), nd = -delta (attn_delta_kernel).  The accumulators start
+    // from the inline constant 0: starting them from -lse / scale and -delta instead (so that the MFMA chain delivers S - lse
+    // and dP - delta) costs 32 register broadcasts per 32-key tile in a loop that is bound by its vector ALU work
+    // (MFMA pipe 0.42-0.45 busy, profiles/r02_attention.json).
+    float nl = 0.f, nd = 0.f;
     if (q_ok) {
-        lse = p.lse[((size_t)b * p.heads + head) * p.N + qi];
-        delta = p.delta[((size_t)b * p.heads + head) * p.N + qi];
+        nd = p.delta[((size_t)b * p.heads + head) * p.N + qi];
+        nl = p.delta[((size_t)p.B + b) * p.heads * p.N + (size_t)head * p.N + qi];
     }
     const float c2 = p.scale * 1.4426950408889634f;
-    const float s_init = -lse / p.scale;
     f32x16 dqt[2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dqt[0][i] = dqt[1][i] = 0.f;
@@ -390,10 +395,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         for (int kt = 0; kt < 2; ++kt) {
             f32x16 s, dp;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s[i] = s_init;
-                dp[i] = -delta;
-            }
+            for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 s = mfma32(read_rows_at(kt_, off_r[st], kt * 32), qf[st], s);
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = fexp2(s[r] * c2) * dp[r];  // dS^T (without the factor `scale`)
+            for (int r = 0; r < 16; ++r) s[r] = fexp2(fmaf(s[r], c2, nl)) * (dp[r] + nd);  // dS^T (without the factor `scale`)
             lds_wait_all();
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
@@ -461,8 +463,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     const bf16* kbase = qbase + C;
     const bf16* vbase = qbase + 2 * C;
     const bf16* gbase = p.d_o + (size_t)b * p.N * C + head * 64;
-    const float* lse_b = p.lse + ((size_t)b * p.heads + head) * p.N;
-    const float* del_b = p.delta + ((size_t)b * p.heads + head) * p.N;
+    const float* del_b = p.delta + ((size_t)b * p.heads + head) * p.N;                 // -delta
+    const float* lse_b = del_b + (size_t)p.B * p.heads * p.N;                          // -lse log2(e)
     const int k0 = tile_x * 128 + wave * 32;
     const int ki = k0 + (lane & 31);
     const int h = lane >> 5;
@@ -483,7 +485,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) dkt[0][i] = dkt[1][i] = dvt[0][i] = dvt[1][i] = 0.f;
     const float c2 = p.scale * 1.4426950408889634f;
-    const float inv_scale = 1.0f / p.scale;
     const int ntile = (p.N + 31) / 32;
     int off_r[4], off_c[2], off_ch[2];
     rows_offsets(lane, off_r);
@@ -510,14 +511,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         const float* st_del = st_lse + 32;
         f32x16 s, dp;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {  // accumulator rows (queries) 8g+4h+{0..3}
-            const f32x4 lv = *(const f32x4*)(st_lse + 8 * g + 4 * h);
-            const f32x4 dv = *(const f32x4*)(st_del + 8 * g + 4 * h);
+        for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;   // (inline-constant accumulator start: see attn_bwd_dq_kernel)
+        f32x4 nl[4], nd[4];                                // accumulator rows (queries) 8g+4h+{0..3}
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s[4 * g + e] = -lv[e] * inv_scale;
-                dp[4 * g + e] = -dv[e];
-            }
+        for (int g = 0; g < 4; ++g) {
+            nl[g] = *(const f32x4*)(st_lse + 8 * g + 4 * h);
+            nd[g] = *(const f32x4*)(st_del + 8 * g + 4 * h);
         }
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
@@ -535,9 +534,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         // queries beyond N have Q = dO = 0, lse = delta = 0  =>  P = 1, dS = 0, and dO^T P adds 0
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = fexp2(s[r] * c2);
+            const float pv = fexp2(fmaf(s[r], c2, nl[r >> 2][r & 3]));
             s[r] = pv;
-            dp[r] = pv * dp[r];
+            dp[r] = pv * (dp[r] + nd[r >> 2][r & 3]);
         }
         lds_wait_all();
 #pragma unroll

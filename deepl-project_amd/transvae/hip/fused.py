@@ -292,7 +292,7 @@ class AttnBranchFn(torch.autograd.Function):
         g = g.contiguous()
         do = conv_dgrad(geo_p, wp, g, o.shape)
         dwp, dbp = _wg(ctx, 4, 5, geo_p, wp, o, g)
-        delta = torch.empty((B, heads, N), dtype=torch.float32, device=t.device)
+        delta = torch.empty((2, B, heads, N), dtype=torch.float32, device=t.device)
         dqkv = torch.empty_like(qkv)
         # (the adjoint of RoPE is applied to dq / dk inside the attention-backward stores)
         L.check(lib.tv_attn_bwd(_p(qkv), _p(o), _p(do), _p(lse), _p(delta), _p(tab), _p(dqkv), B, N, heads, scale, _stream()),

@@ -799,7 +799,7 @@ class AttentionFn(torch.autograd.Function):
         heads = ctx.heads
         lib = L.load()
         go = go.contiguous()
-        delta = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+        delta = torch.empty((2, B, heads, N), dtype=torch.float32, device=qkv.device)   # scratch: -delta, -lse log2(e)
         dqkv = torch.empty_like(qkv)
         L.check(lib.tv_attn_bwd(_p(qkv), _p(o), _p(go), _p(lse), _p(delta), None, _p(dqkv), B, N, heads, ctx.scale, _stream()),
                 "tv_attn_bwd")

@@ -178,7 +178,7 @@ int tv_rope_qk(void* qkv, const float* tab, int B, int N, int heads, int transpo
  * qkv [B,N,3,heads,64] bf16; o [B,N,heads,64] bf16; lse [B,heads,N] fp32 (natural log). */
 int tv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int heads, float scale,
                 void* stream);
-/* dqkv [B,N,3,heads,64] bf16 from do; delta [B,heads,N] fp32 is scratch.  rope_tab (may be NULL): the table of tv_rope_qk;
+/* dqkv [B,N,3,heads,64] bf16 from do; delta [2,B,heads,N] fp32 is scratch (the kernels keep -delta and -lse log2(e) there).  rope_tab (may be NULL): the table of tv_rope_qk;
  * when given, q and k in `qkv` are the ROTATED projections (tv_igemm_nt_rope) and dq / dk are stored as gradients w.r.t.
  * the un-rotated ones (the adjoint of attention.py:156-197 applied to the fp32 accumulators in the store). */
 int tv_attn_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,

@@ -572,7 +572,7 @@ def test_qkv_projection_with_rope_in_the_epilogue_and_adjoint_in_attention_backw
     do = gen(B, N, Cc, seed=4).to(dev(), BF)
     res = []
     for fused_adjoint in (True, False):
-        delta = torch.empty((B, heads, N), dtype=torch.float32, device=dev())
+        delta = torch.empty((2, B, heads, N), dtype=torch.float32, device=dev())
         dqkv = torch.empty_like(qkv)
         _lib.check(lib.tv_attn_bwd(ops._p(qkv), ops._p(o), ops._p(do), ops._p(lse), ops._p(delta), ops._p(tabd) if fused_adjoint else None,
                                    ops._p(dqkv), B, N, heads, 0.125, None))
