@@ -610,3 +610,63 @@ def test_attention_fwd_bwd(B, H, W, heads, rope):
     g = xd.grad.cpu().float()
     for i, nm in enumerate("qkv"):
         assert rel(g[..., i * C:(i + 1) * C], x.grad[..., i * C:(i + 1) * C]) < 2e-2, f"d{nm}"
+
+
+# ---- register epilogues (igemm_common.h: EF_*) against the generic LDS loop ---------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(0, 0, 0, 0), (256, 256, 0, 0), (256, 192, 0, 0), (128, 128, 0, 0)])
+def test_register_epilogue_forms_are_bit_identical_to_the_lds_loop(cfg):
+    """Every compact register form (plain, GELU / SiLU, with saved derivative, residual add, derivative multiply,
+    (acc + residual) x derivative, RoPE) must round exactly like the generic LDS loop it replaces, on every tile shape --
+    a batch has to equal its images run alone bit for bit and the tile shape depends on the batch
+    (test_large_f16d32_256_full_size_properties_and_oracle caught an fma contraction that differed between two
+    instantiations).  Shapes: ragged M (tail rows masked), N = 384 (96-wide slabs on the 192 tiles: odd line alignment,
+    a block without a line partner), linear layers and a 3x3 convolution through the halo kernel."""
+    from transvae.hip import _lib as L, ops
+    lib = L.load()
+    g = torch.Generator(device=dev()).manual_seed(5)
+    bf = torch.bfloat16
+    M, K, N = 2 * 1024 + 40, 192, 384
+    x = torch.randn(M, K, device=dev(), generator=g).to(bf)
+    w = torch.randn(N, K, device=dev(), generator=g) * K ** -0.5
+    b = torch.randn(N, device=dev(), generator=g) * 0.1
+    res = torch.randn(M, N, device=dev(), generator=g).to(bf)
+    gz = torch.randn(M, N, device=dev(), generator=g).to(bf)
+    der = torch.rand(M, K, device=dev(), generator=g).to(bf)
+    gres = torch.randn(M, K, device=dev(), generator=g).to(bf)
+    tab = torch.randn(1024, 4, 32, device=dev(), generator=g)
+    xc = torch.randn(3, 32, 32, 192, device=dev(), generator=g).to(bf)
+    wc = torch.randn(192, 3, 3, 192, device=dev(), generator=g) * (9 * 192) ** -0.5
+    bc = torch.randn(192, device=dev(), generator=g) * 0.1
+    geo = ops._Geo("linear", x, w)
+    xr = x[: 2 * 1024].contiguous()
+
+    def cases():
+        out = {}
+        out["plain"] = ops.conv_forward(x, w, b, None, "linear", L.ACT_NONE, False)[0]
+        out["gelu"] = ops.conv_forward(x, w, b, None, "linear", L.ACT_GELU, False)[0]
+        out["silu"] = ops.conv_forward(x, w, b, None, "linear", L.ACT_SILU, False)[0]
+        y, d = ops.conv_forward(x, w, b, None, "linear", L.ACT_GELU, "deriv")[:2]
+        out["gelu+deriv"], out["gelu+deriv:saved"] = y, d
+        y, d = ops.conv_forward(x, w, b, None, "linear", L.ACT_SILU, "deriv")[:2]
+        out["silu+deriv"], out["silu+deriv:saved"] = y, d
+        out["residual"] = ops.conv_forward(x, w, b, res, "linear", L.ACT_NONE, False)[0]
+        out["dgrad"] = ops.conv_dgrad(geo, w, gz, x.shape)
+        out["dgrad*deriv"] = ops.conv_dgrad(geo, w, gz, x.shape, aux=der, aux_act=L.ACT_DERIV)
+        out["(dgrad+res)*deriv"] = ops.conv_dgrad(geo, w, gz, x.shape, residual=gres, aux=der, aux_act=L.ACT_DERIV)
+        out["rope"] = ops.conv_forward(xr, w, b, None, "linear", L.ACT_NONE, False, rope=(tab, 1024, 256))[0]
+        out["conv3x3 gelu+deriv"] = ops.conv_forward(xc, wc, bc, None, "c3s1", L.ACT_GELU, "deriv")[0]
+        out["conv3x3 residual"] = ops.conv_forward(xc, wc, bc, xc, "c3s1", L.ACT_NONE, False)[0]
+        return out
+    try:
+        lib.tv_set_igemm_config(*cfg)
+        lib.tv_set_igemm_epilogue(1)
+        reg = cases()
+        lib.tv_set_igemm_epilogue(0)
+        lds = cases()
+    finally:
+        lib.tv_set_igemm_epilogue(1)
+        lib.tv_set_igemm_config(0, 0, 0, 0)
+    for k in reg:
+        assert torch.isfinite(reg[k].float()).all(), k
+        assert torch.equal(reg[k], lds[k]), (k, cfg, float((reg[k].float() - lds[k].float()).abs().max()))
