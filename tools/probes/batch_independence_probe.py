@@ -1,3 +1,10 @@
+"""Where does a batch stop being bit-equal to its images run alone?  (GPU box; diagnostic.)
+
+Runs TransVAE-Large's encoder on 2 images and on the first image alone, reports the first stage whose output differs, then
+takes the stage-2 block apart (row norm, QKV with and without the RoPE epilogue, attention branch, FFN branch) per tile
+configuration and per epilogue mode (register forms vs the generic LDS loop).  Written when an fma contraction that differed
+between two tile-shape instantiations of the RoPE epilogue broke tests/test_model_gpu.py::test_large_f16d32_256_full_size_
+properties_and_oracle."""
 import os, sys, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/deepl-project_amd")
 import bench
