@@ -88,7 +88,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
         const int n = n0 + row;
         return (n < p.N) ? (n * p.K + c) * 2 : OOB_OFFSET;
     };
+#ifdef TV_ABL_K1   // (ablation: one channel chunk = 9 of the 27 tap steps at 192 channels: fixed costs by difference)
+    const int cch = 1;
+#else
     const int cch = p.c_in / BK;
+#endif
 
     // where the registers allow, the offsets are computed once (the recomputation is ~12 VALU operations per piece in the
     // middle of the MFMA stream)
@@ -555,6 +559,16 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
 
     if (TV_SETPRIO) __builtin_amdgcn_s_setprio(0);
     TV_T(5);
+#ifdef TV_ABL_NO_EPI   // (ablation: main loop only)
+    {
+        float chk = 0.f;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) chk += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (chk != 123.456f) return;
+    }
+#endif
     f32x4 bvals[NF];
     load_bias<WTN>(p, lane, n0 + wn * WTN, bvals);
     // wave-tile row r -> output pixel: fragment row i = r / 16 is tile row wm*MF + i, r % 16 the column
