@@ -54,6 +54,29 @@ __device__ __forceinline__ void stage_rows(char* lds, const bf16* base, int g0, 
     }
 }
 
+// The same staging through a buffer descriptor (tensors < 2 GiB per image): the per-lane offset of a piece inside the tile
+// (row, swizzled chunk) is fixed for the whole kernel, the tile's first row enters as the SCALAR offset and rows beyond
+// `nvalid` fall outside the descriptor's extent (the DMA writes zeros) -- no vector ALU work per tile.  The per-tile address
+// arithmetic of stage_rows (64-bit multiply-add, bound check, select: ~15 operations per KiB piece) was a sixth of the
+// instructions of loops that are bound by their vector ALU work (profiles/r02_attention.json).
+template <bool TR, int NP>
+__device__ __forceinline__ void stage_offsets(int (&voff)[NP], int ld, int wave, int lane) {
+    const int rsub = lane >> 3, slot = lane & 7;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int row = (wave + 4 * q) * 8 + rsub;
+        const int c = slot ^ (TR ? swz_tr(row) : swz_row(row));
+        voff[q] = (row * ld + c * 8) * 2;
+    }
+}
+template <int NP>
+__device__ __forceinline__ void stage_rows_buf(char* lds, const bf16* base, unsigned bytes, int g0, int ld, const int (&voff)[NP], int wave) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) buffer_load_lds16(base, bytes, lds + (wave + 4 * q) * 1024, voff[q], g0 * ld * 2);
+}
+// extent of a [nvalid, 64] head slice of a matrix with row pitch ld (elements), from the slice's first element
+__device__ __forceinline__ unsigned stage_extent(int nvalid, int ld) { return (unsigned)(((long long)(nvalid - 1) * ld + 64) * 2); }
+
 // A operand (32 rows x 16 k) read by rows: lane (row = lane&31, half h) takes 16 bytes at d = 16*st + 8*h
 __device__ __forceinline__ bf16x8 read_rows(const char* tile, int row0, int st, int lane) {
     const int row = row0 + (lane & 31);
@@ -202,15 +225,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     int off_k[4], off_v[2], off_vh[2];
     rows_offsets(lane, off_k);
     cols_offsets<true>(lane, off_v, off_vh);
-    stage_rows<false>(smem, kbase, 0, p.N, ld, 64, wave, lane, p.zeros);
-    stage_rows<true>(smem + KV_TILE, vbase, 0, p.N, ld, 64, wave, lane, p.zeros);
+    int vo_k[2], vo_v[2];
+    stage_offsets<false>(vo_k, (int)ld, wave, lane);
+    stage_offsets<true>(vo_v, (int)ld, wave, lane);
+    const unsigned kv_bytes = stage_extent(p.N, (int)ld);
+    stage_rows_buf(smem, kbase, kv_bytes, 0, (int)ld, vo_k, wave);
+    stage_rows_buf(smem + KV_TILE, vbase, kv_bytes, 0, (int)ld, vo_v, wave);
     for (int t = 0; t < nblk; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nblk) {
             char* nb = smem + ((t + 1) & 1) * 2 * KV_TILE;
-            stage_rows<false>(nb, kbase, (t + 1) * 64, p.N, ld, 64, wave, lane, p.zeros);
-            stage_rows<true>(nb + KV_TILE, vbase, (t + 1) * 64, p.N, ld, 64, wave, lane, p.zeros);
+            stage_rows_buf(nb, kbase, kv_bytes, (t + 1) * 64, (int)ld, vo_k, wave);
+            stage_rows_buf(nb + KV_TILE, vbase, kv_bytes, (t + 1) * 64, (int)ld, vo_v, wave);
         }
         const char* kt_ = smem + (t & 1) * 2 * KV_TILE;
         const char* vt_ = kt_ + KV_TILE;
@@ -377,15 +404,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     rows_offsets(lane, off_r);
     cols_offsets<false>(lane, off_c, off_ch);
 
-    stage_rows<false>(smem, kbase, 0, p.N, ld, 64, wave, lane, p.zeros);
-    stage_rows<false>(smem + KV_TILE, vbase, 0, p.N, ld, 64, wave, lane, p.zeros);
+    int vo_kv[2];
+    stage_offsets<false>(vo_kv, (int)ld, wave, lane);
+    const unsigned kv_bytes = stage_extent(p.N, (int)ld);
+    stage_rows_buf(smem, kbase, kv_bytes, 0, (int)ld, vo_kv, wave);
+    stage_rows_buf(smem + KV_TILE, vbase, kv_bytes, 0, (int)ld, vo_kv, wave);
     for (int t = 0; t < nblk; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nblk) {
             char* nb = smem + ((t + 1) & 1) * 2 * KV_TILE;
-            stage_rows<false>(nb, kbase, (t + 1) * 64, p.N, ld, 64, wave, lane, p.zeros);
-            stage_rows<false>(nb + KV_TILE, vbase, (t + 1) * 64, p.N, ld, 64, wave, lane, p.zeros);
+            stage_rows_buf(nb, kbase, kv_bytes, (t + 1) * 64, (int)ld, vo_kv, wave);
+            stage_rows_buf(nb + KV_TILE, vbase, kv_bytes, (t + 1) * 64, (int)ld, vo_kv, wave);
         }
         const char* kt_ = smem + (t & 1) * 2 * KV_TILE;
         const char* vt_ = kt_ + KV_TILE;
@@ -490,9 +520,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     rows_offsets(lane, off_r);
     cols_offsets<false>(lane, off_c, off_ch);
 
+    int vo_q[1], vo_g[1];
+    stage_offsets<false>(vo_q, (int)ld, wave, lane);
+    stage_offsets<false>(vo_g, C, wave, lane);
+    const unsigned q_bytes = stage_extent(p.N, (int)ld), g_bytes = stage_extent(p.N, C);
     auto stage = [&](int t, char* sb) {
-        stage_rows<false>(sb, qbase, t * 32, p.N, ld, 32, wave, lane, p.zeros);
-        stage_rows<false>(sb + QT_TILE, gbase, t * 32, p.N, (size_t)C, 32, wave, lane, p.zeros);
+        stage_rows_buf(sb, qbase, q_bytes, t * 32, (int)ld, vo_q, wave);
+        stage_rows_buf(sb + QT_TILE, gbase, g_bytes, t * 32, C, vo_g, wave);
         if (wave == 0) {  // lanes 0-31: lse, lanes 32-63: delta (4-byte LDS-DMA)
             const int q = t * 32 + (lane & 31);
             const float* src = (q < p.N) ? ((lane < 32 ? lse_b : del_b) + q) : (const float*)(p.zeros + lane * 4);
@@ -580,6 +614,7 @@ int attn_check(const char* name, int B, int N, int heads, float scale) {
 extern "C" int tv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int heads, float scale, void* stream) {
     if (attn_check("tv_attn_fwd", B, N, heads, scale)) return TV_ERR_ARG;
     TV_CHECK_ARG(qkv && o && lse, "tv_attn_fwd: null pointer");
+    TV_CHECK_ARG((long long)N * heads * 64 * 3 * 2 < (1ll << 31), "tv_attn_fwd: one image's qkv must stay below 2 GiB (32-bit DMA offsets)");
     if (tv_init() != TV_OK) return TV_ERR_INIT;
     AttnArgs a{};
     a.qkv = (const bf16*)qkv; a.out = (bf16*)o; a.lse = lse; a.zeros = (const char*)tv_zero_page();
@@ -594,6 +629,7 @@ extern "C" int tv_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
                            void* dqkv, int B, int N, int heads, float scale, void* stream) {
     if (attn_check("tv_attn_bwd", B, N, heads, scale)) return TV_ERR_ARG;
     TV_CHECK_ARG(qkv && o && d_o && lse && delta && dqkv, "tv_attn_bwd: null pointer");
+    TV_CHECK_ARG((long long)N * heads * 64 * 3 * 2 < (1ll << 31), "tv_attn_bwd: one image's qkv must stay below 2 GiB (32-bit DMA offsets)");
     if (tv_init() != TV_OK) return TV_ERR_INIT;
     AttnArgs a{};
     a.qkv = (const bf16*)qkv; a.o = (const bf16*)o; a.d_o = (const bf16*)d_o; a.out = (bf16*)dqkv;
