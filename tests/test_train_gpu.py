@@ -5,6 +5,7 @@ fused autograd Functions are the same).
 
 Reference call pattern: R/train.py:557-646 (accumulate, clip, AdamW), R/train_2.py:266-273,303-338 (bf16 policy,
 logvar clamp, skip on non-finite), P/.../transvae.py:186-196,243-245 (clamps)."""
+import math
 import os
 import socket
 
@@ -504,3 +505,33 @@ def test_resume_from_a_reference_written_checkpoint(golden_dir):
         back = torch.load(out, weights_only=True)
         assert float(back["optimizer_state_dict"]["state"][0]["step"]) == 2.0
         assert set(back["optimizer_state_dict"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_launch_as_the_driver_does_it():
+    """The N > 1 contract of bench.py end to end, launched the way the driver launches it
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ... bench.py --gpus 2 ...):
+    rendezvous, one rank per process, DDP over the fused autograd Functions with the HIP optimizer, barrier + max-over-ranks
+    timing, ONE JSON line from rank 0.  On a one-GPU box both ranks share cuda:0 over gloo (TV_BENCH_REHEARSE=1: RCCL refuses
+    two ranks on one device); everything else is the code path of the 8-GPU run.  Small model, 2 steps."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, TV_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--variant", "tiny", "--res", "64", "--global-batch", "8", "--micro-batch", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only, one line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["scaling"] == "strong" and out["unit"] == "images/sec" and out["value"] > 0
+    assert out["skipped_steps"] == 0 and math.isfinite(out["final_loss"])
+    assert out["config"]["global_batch"] == 8
