@@ -1,0 +1,441 @@
+// Weight gradient of 3x3 / stride-1 / pad-1 convolutions on image rows of >= 64 pixels ("kx-triple", round 3):
+//
+//     dw[co][ky][kx][ci] += sum_p gy[p][co] * x[p + (ky-1) w + (kx-1)][ci]          dbias[co] += sum_p gy[p][co]
+//
+// (R/transvae/modules/blocks.py:34,37: autograd of the two ResBlock convolutions; R/transvae/modules/conv.py:58: the 3x3
+// of the Conv-FFN; R/transvae/modules/upsample.py:33,97: the stride-1 convolutions of Down/Upsample.)
+//
+// Why a second kernel.  The single-tap kernel (wgrad_tn.hip) stages gy and x once PER TAP: 48 KiB of LDS-DMA per 4.7 MFLOP
+// K-step on its 192x192 tile = 96 FLOP per staged byte.  A CU sustains ~40 GB/s of LDS-DMA next to its matrix work
+// (profiles/r02_gemm_sweep_mb64.txt: 999 TFLOP/s = 40 GB/s x 96 FLOP/B x 256 CUs), so that kernel runs AT its fill rate.
+// Here a block owns (co tile, ky, ci tile) for all THREE kx: a K-step stages 64 output pixels of gy (one piece of an image
+// row) and the matching 64 + 2 input pixels of x ONCE; tap kx reads its x fragments from the same LDS image shifted by kx
+// rows.  With a 192 (co) x 96 (ci) x 3 (kx) tile that is 37 KiB per 7.1 MFLOP = 187 FLOP per staged byte, and each wave
+// (48 co x 48 ci x 3 kx) issues 54 MFMAs per 48 transposing reads instead of 36 per 36.
+//
+// Structure: 8 waves, wave-group ping-pong (the main loop of conv3x3_halo_kernel): waves w and w + 4 share a SIMD; group 0
+// reads the fragments of K-step t and issues its LDS-DMA pieces while group 1 multiplies step t - 1, then they swap: one
+// block barrier per phase.  LDS: a ring of RING stages (gy slots first, x slots after), K-step t + RING - 1 is issued during
+// step t.  Every fragment read is `base register + immediate`: the ring slot, the 32-pixel half of the step and the
+// 4-pixel half of the fragment are compile-time offsets (the step loop is unrolled RING times), so the load phase has no
+// address arithmetic.
+//
+// x image of a K-step: tile row 0 = left neighbour of the segment (zeros at the image's left edge: out-of-range DMA
+// offset = the convolution's zero padding), rows 1..64 = the 64 pixels, row 65 = right neighbour; padding in y = the
+// whole step's x rows out of range.  Tiles are pixel-major ([row][channels], 16-byte chunks XOR-swizzled on the DMA source
+// address and on the read address), fragments come out through ds_read_b64_tr_b16.
+#include "common.h"
+
+#include <type_traits>
+
+namespace {
+
+struct Kx3Args {
+    const bf16* x;
+    const bf16* gy;
+    float* dw;
+    float* dbias;
+    int M, h, w, c_in, ldx, c_out, ldo;
+    int tiles_ci, chunk_px, hw_shift, w_shift, plain;
+    int xcd_order, base, ny, accum;
+    unsigned x_bytes;
+};
+
+// physical 16-byte slot of logical chunk c in row r of a [rows][TW channels] tile: conflict-free transposing reads for ANY
+// first row of the 4-row blocks (the x image is read at row offsets 0 / 1 / 2)
+template <int TW>
+__device__ __forceinline__ int kx_swz(int c, int r) {
+    if constexpr (TW % 128 == 0) {
+        const int s = (((r >> 3) & 1) << 3) | ((r & 3) << 1);
+        return (c & ~15) | ((c & 15) ^ s);
+    } else if constexpr (TW % 64 == 0) {
+        const int s = (((r >> 3) & 1) << 2) | (((r >> 1) & 1) << 1);
+        return (c & ~7) | ((c & 7) ^ s);
+    } else {   // 96: rows of 6 x 32 bytes; consecutive rows are 6 bank groups apart, rows 8 apart collide -> XOR bit 1
+        static_assert(TW % 32 == 0, "tile width");
+        const int s = ((r >> 3) & 1) << 1;
+        return (c & ~3) | ((c & 3) ^ s);
+    }
+}
+
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_tr16(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    bf16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int kx_xrows(int cx) {   // >= 66 rows and a whole number of 1 KiB DMA pieces
+    int r = 66;
+    while ((r * cx) % 64 != 0) ++r;
+    return r;
+}
+
+template <int TG, int TX, int NWM, int NWN, int RING>
+__global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
+    constexpr int NW = 8, BKP = 64;
+    static_assert(NWM * NWN == NW, "8 waves");
+    constexpr int CG = TG / 8, CX = TX / 8;
+    constexpr int XROWS = kx_xrows(CX);
+    constexpr int G_PIECES = BKP * CG / 64;                    // 1 KiB pieces of the gy tile
+    constexpr int X_PIECES = (66 * CX + 63) / 64;              // ... of the 66 used rows of the x tile
+    static_assert(G_PIECES % NW == 0, "gy pieces divide over the waves");
+    constexpr int G_IT = G_PIECES / NW, X_IT = (X_PIECES + NW - 1) / NW;
+    constexpr int G_BYTES = BKP * TG * 2, X_BYTES = XROWS * TX * 2;
+    constexpr int X_REGION = RING * G_BYTES;
+    static_assert(RING * (G_BYTES + X_BYTES) <= 160 * 1024, "LDS");
+    constexpr int WTG = TG / NWM, WTX = TX / NWN, MF = WTG / 16, NF = WTX / 16;
+    static_assert(WTG % 16 == 0 && WTX % 16 == 0, "wave tile");
+    constexpr int LOOK = RING - 1;
+    constexpr int SURE = G_IT + X_PIECES / NW;                 // pieces EVERY wave issues per K-step (low waves may issue one more)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+
+    int bx, chunk_id;
+    if (p.xcd_order) {   // all (co, ky, ci) tiles of a pixel chunk on one XCD: they share gy / x through its L2
+        const int lin = blockIdx.x;
+        const int xcd = lin & 7, j = lin >> 3;
+        bx = j % p.base;
+        chunk_id = (j / p.base) * 8 + xcd;
+        if (chunk_id >= p.ny) return;
+    } else {
+        bx = blockIdx.x;
+        chunk_id = blockIdx.y;
+    }
+    const int ci_tile = bx % p.tiles_ci;
+    bx /= p.tiles_ci;
+    const int ky = bx % 3;
+    const int co_tile = bx / 3;
+    const int co0 = co_tile * TG, ci0 = ci_tile * TX;
+    const int p_begin = chunk_id * p.chunk_px;
+    const int p_end = min(p.M, p_begin + p.chunk_px);
+    const int nsteps = (p_end - p_begin) / BKP;                // (M and the chunk size are multiples of 64: host)
+    if (nsteps <= 0) return;
+    const int w = p.w, hw = p.h * p.w;
+    const int dty = ky - 1;
+
+    // ---- staging bookkeeping (fixed per thread) ---------------------------------------------------------------------------
+    int g_voff[G_IT];
+#pragma unroll
+    for (int it = 0; it < G_IT; ++it) {
+        const int id = (it * NW + wave) * 64 + lane;
+        const int r = id / CG, sl = id - r * CG;
+        g_voff[it] = (r * p.ldo + co0 + kx_swz<TG>(sl, r) * 8) * 2;
+    }
+    int x_voff[X_IT], x_need[X_IT];     // need: bit 0 = pixel of the segment, bit 1 = left neighbour, bit 2 = right neighbour; 0 = unused row
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+        const int id = (it * NW + wave) * 64 + lane;
+        const int R = id / CX, sl = id - R * CX;
+        x_need[it] = R == 0 ? 2 : (R == 65 ? 4 : (R > 65 ? 0 : 1));
+        x_voff[it] = (R * p.ldx + ci0 + kx_swz<TX>(sl, R) * 8) * 2;            // relative to pixel (pz + dty w - 1)
+    }
+    const long long dshift = ((long long)dty * w - 1) * p.ldx;                 // elements
+    const bf16* xb = p.x + dshift;
+    const unsigned xb_bytes = (unsigned)((long long)p.x_bytes - dshift * 2);
+    const unsigned g_bytes = (unsigned)((long long)p_end * p.ldo * 2);
+
+    auto stage_issue = [&](int step, int slot) {
+        const int pz = p_begin + step * BKP;
+        char* gdst = smem + slot * G_BYTES;
+        char* xdst = smem + X_REGION + slot * X_BYTES;
+#pragma unroll
+        for (int it = 0; it < G_IT; ++it)
+            buffer_load_lds16(p.gy, g_bytes, gdst + (it * NW + wave) * 1024, g_voff[it], pz * p.ldo * 2);
+        const int x0 = pz & (w - 1);
+        const int uy = ((pz & (hw - 1)) >> p.w_shift) + dty;
+        const bool row_ok = (unsigned)uy < (unsigned)p.h;
+        // (one scalar mask per step against one per-lane bit: no divergent control flow around the DMA issue)
+        const int have = row_ok ? (1 | (x0 != 0 ? 2 : 0) | (x0 + BKP < w ? 4 : 0)) : 0;
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            if (X_PIECES % NW != 0 && it * NW + wave >= X_PIECES) break;
+            buffer_load_lds16(xb, xb_bytes, xdst + (it * NW + wave) * 1024, (x_need[it] & have) ? x_voff[it] : OOB_OFFSET, pz * p.ldx * 2);
+        }
+    };
+
+    // ---- fragment addressing: lane (g = lane>>4, q = (lane>>2)&3, pp = lane&3) supplies row 8g + 4h + q (+ 32 kk), columns
+    // base + 4pp .. +3 of a 32-pixel slice.  Everything but the lane's own part is an immediate.
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned a_base[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        const int r = 8 * g + q;
+        const int col = wm * WTG + i * 16 + 4 * pp;
+        a_base[i] = smem_addr + r * (TG * 2) + kx_swz<TG>(col >> 3, r) * 16 + (pp & 1) * 8;
+    }
+    unsigned b_base[2][3][NF];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+            const int R = 8 * g + 4 * h + q + tp;                 // tile row of tap kx = tp for pixel 8g + 4h + q
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int col = wn * WTX + j * 16 + 4 * pp;
+                b_base[h][tp][j] = smem_addr + X_REGION + R * (TX * 2) + kx_swz<TX>(col >> 3, R) * 16 + (pp & 1) * 8;
+            }
+        }
+    // (a slot offset beyond the 16-bit field: second base registers for the upper half of the ring)
+    constexpr int A_SPAN = (RING - 1) * G_BYTES + 32 * TG * 2 + 4 * TG * 2;
+    constexpr bool A_TWO = A_SPAN >= 65536;
+    static_assert((RING - 1) * X_BYTES + 32 * TX * 2 < 65536, "x slot offsets fit the immediate");
+    static_assert(!A_TWO || ((RING - 3) * G_BYTES + 32 * TG * 2 + 4 * TG * 2 < 65536), "gy slot offsets");
+    unsigned a_base2[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) a_base2[i] = a_base[i] + (A_TWO ? 2 * G_BYTES : 0);
+
+    f32x4 acc[3][MF][NF];
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[tp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // bias gradient = column sums of gy: the gy fragments are in registers anyway (lane L holds 8 pixels of output channel
+    // L & 15), the owning waves add them up with vector ALU work in their LOAD phase.  Owners: the blocks of (ky = 1, ci tile 0);
+    // fragment i of a wave row belongs to the wave with wn == i % NWN.
+    const bool do_bias = (p.dbias != nullptr) && ci_tile == 0 && ky == 1;
+    constexpr int NB = (MF + NWN - 1) / NWN;
+    float bsum[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) bsum[k] = 0.f;
+
+    auto join = [](bf16x4 lo, bf16x4 hi) { return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
+    bf16x4 alo[2][MF], ahi[2][MF], blo[2][3][NF], bhi[2][3][NF];
+    const int grp = wave >> 2;
+
+#pragma unroll
+    for (int st = 0; st < LOOK; ++st)
+        if (st < nsteps) stage_issue(st, st);
+    wait_vm<0>();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+    // one K-step with the ring slot as a compile-time constant
+    auto step = [&](int t, auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int A_OFF = (A_TWO && SLOT >= 2) ? (SLOT - 2) * G_BYTES : SLOT * G_BYTES;
+        // ---- load phase ----------------------------------------------------------------------------------------------------
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const unsigned ab = (A_TWO && SLOT >= 2) ? a_base2[i] : a_base[i];
+                if (kk == 0) {
+                    alo[0][i] = lds_tr16<A_OFF>(ab);
+                    ahi[0][i] = lds_tr16<A_OFF + 4 * TG * 2>(ab);
+                } else {
+                    alo[1][i] = lds_tr16<A_OFF + 32 * TG * 2>(ab);
+                    ahi[1][i] = lds_tr16<A_OFF + 32 * TG * 2 + 4 * TG * 2>(ab);
+                }
+            }
+#pragma unroll
+            for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    if (kk == 0) {
+                        blo[0][tp][j] = lds_tr16<SLOT * X_BYTES>(b_base[0][tp][j]);
+                        bhi[0][tp][j] = lds_tr16<SLOT * X_BYTES>(b_base[1][tp][j]);
+                    } else {
+                        blo[1][tp][j] = lds_tr16<SLOT * X_BYTES + 32 * TX * 2>(b_base[0][tp][j]);
+                        bhi[1][tp][j] = lds_tr16<SLOT * X_BYTES + 32 * TX * 2>(b_base[1][tp][j]);
+                    }
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = t + LOOK < nsteps;
+        if (more) stage_issue(t + LOOK, (SLOT + LOOK) % RING);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_bias) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+                    if (i % NWN == wn) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a += (float)alo[kk][i][e] + (float)ahi[kk][i][e];
+                        bsum[i / NWN] += a;
+                    }
+        }
+        // the pieces of K-step t+1 (issued LOOK-1 load phases ago) have landed; younger ones may stay in flight
+        if (!more) wait_vm<0>();
+        else if (X_PIECES % NW != 0 && wave < X_PIECES % NW) wait_vm<(LOOK - 1) * (SURE + 1)>();
+        else wait_vm<(LOOK - 1) * SURE>();
+        // ---- MFMA phase ----------------------------------------------------------------------------------------------------
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const bf16x8 af = join(alo[kk][i], ahi[kk][i]);
+#pragma unroll
+                for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, join(blo[kk][tp][j], bhi[kk][tp][j]), acc[tp][i][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    for (int t = 0; t < nsteps; t += RING) {
+        step(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nsteps) step(t + 1, std::integral_constant<int, 1>{});
+        if (t + 2 < nsteps) step(t + 2, std::integral_constant<int, 2 % RING>{});
+        if constexpr (RING == 4) {
+            if (t + 3 < nsteps) step(t + 3, std::integral_constant<int, 3 % RING>{});
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- fp32 results into dw[co][ky*3 + kx][ci]; D layout: row = (lane>>4)*4 + reg (co), col = lane&15 (ci)
+    const size_t ldw = (size_t)9 * p.c_in;
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + wm * WTG + i * 16 + g * 4 + r;
+#pragma unroll
+            for (int tp = 0; tp < 3; ++tp) {
+                float* rowp = p.dw + (size_t)co * ldw + (size_t)(ky * 3 + tp) * p.c_in;
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    const int ci = ci0 + wn * WTX + j * 16 + (lane & 15);
+                    if (p.plain && !p.accum) rowp[ci] = acc[tp][i][j][r];
+                    else if (p.plain) rowp[ci] += acc[tp][i][j][r];
+                    else atomicAdd(rowp + ci, acc[tp][i][j][r]);
+                }
+            }
+        }
+    }
+    if (do_bias) {   // lanes L, L+16, L+32, L+48 hold partial sums of the same output channel
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+            if (i % NWN == wn) {
+                float v = bsum[i / NWN];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                const int co = co0 + wm * WTG + i * 16 + (lane & 15);
+                if (lane < 16) {
+                    if (p.plain && !p.accum) p.dbias[co] = v;
+                    else if (p.plain) p.dbias[co] += v;
+                    else atomicAdd(p.dbias + co, v);
+                }
+            }
+    }
+}
+
+int g_kx3_ring = 0;     // 0 = default (4 where it fits), 3 / 4: A/B
+int g_kx3_blocks = 0;   // 0 = cost model, else target number of blocks
+
+template <int TG, int TX, int NWM, int NWN, int RING>
+int kx3_launch_r(Kx3Args a, hipStream_t s, bool plan_only) {
+    constexpr int BYTES = RING * (64 * TG * 2 + kx_xrows(TX / 8) * TX * 2);
+    const int tiles_co = a.c_out / TG;
+    a.tiles_ci = a.c_in / TX;
+    const long long base = (long long)tiles_co * 3 * a.tiles_ci;
+    // split-K over pixel chunks: one block per CU; with the XCD-grouped order a chunk's `base` tiles share an XCD (32 CUs).
+    // minimise  rounds x (pixels per block) x t_pixel  +  atomic bytes / 1.3 TB/s  (MI355X_MICROARCH "Global float atomics")
+    const double t_px = 2.0 * TG * TX * 3 * 256.0 / 1200e12;
+    const double tile_bytes = 4.0 * TG * TX * 3;
+    long long split = 1;
+    bool xcd = false;
+    double best = 1e30;
+    const long long smax = a.M / 512 > 0 ? a.M / 512 : 1;
+    if (g_kx3_blocks) {
+        split = (g_kx3_blocks + base - 1) / base;
+        xcd = base <= 32 && split >= 8;
+    } else {
+        for (long long sp = 1; sp <= smax && sp <= 4096; ++sp) {
+            const double rounds = (double)((long long)((base * sp + 255) / 256));
+            const double t = rounds * ((double)a.M / sp) * t_px + (sp > 1 ? base * sp * tile_bytes / 1.3e12 : 0.0);
+            if (t < best) { best = t; split = sp; xcd = false; }
+        }
+        if (base <= 32) {
+            for (long long sp = 8; sp <= smax && sp <= 4096; sp += 8) {
+                const double rounds = (double)((long long)((base * (sp / 8) + 31) / 32));
+                const double t = rounds * ((double)a.M / sp) * (t_px * 0.85) + base * sp * tile_bytes / 1.3e12;
+                if (t < best) { best = t; split = sp; xcd = true; }
+            }
+        }
+    }
+    long long chunk = (a.M + split - 1) / split;
+    if (chunk < 512) chunk = 512;
+    chunk = (chunk + 63) / 64 * 64;
+    a.chunk_px = (int)chunk;
+    const int ny = (int)((a.M + chunk - 1) / chunk);
+    a.plain = (ny == 1) ? 1 : 0;
+    if (plan_only) return 100 + a.plain;
+    a.base = (int)base;
+    a.ny = ny;
+    a.xcd_order = (ny > 1 && xcd) ? 1 : 0;
+    dim3 grid((unsigned)base, (unsigned)ny);
+    if (a.xcd_order) grid = dim3((unsigned)(8 * base * ((ny + 7) / 8)), 1);
+    static TvPerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute((const void*)wgrad_kx3_kernel<TG, TX, NWM, NWN, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    }
+    hipLaunchKernelGGL((wgrad_kx3_kernel<TG, TX, NWM, NWN, RING>), grid, dim3(512), BYTES, s, a);
+    return 0;
+}
+
+template <int TG, int TX, int NWM, int NWN>
+int kx3_launch(const Kx3Args& a, hipStream_t s, bool plan_only) {
+    constexpr int STAGE = 64 * TG * 2 + kx_xrows(TX / 8) * TX * 2;
+    if constexpr (4 * STAGE <= 160 * 1024) {
+        if (g_kx3_ring != 3) return kx3_launch_r<TG, TX, NWM, NWN, 4>(a, s, plan_only);
+    }
+    return kx3_launch_r<TG, TX, NWM, NWN, 3>(a, s, plan_only);
+}
+
+}  // namespace
+
+// A/B hooks (tools/, tests): ring depth (0 = default, 3, 4), block target for the split-K choice (0 = cost model)
+extern "C" int tv_set_wgrad_kx3(int enable, int ring, int blocks);
+int g_kx3_enable = 1;
+extern "C" int tv_set_wgrad_kx3(int enable, int ring, int blocks) {
+    g_kx3_enable = enable;
+    g_kx3_ring = ring;
+    g_kx3_blocks = blocks;
+    return 0;
+}
+
+// Called by wgrad_impl (wgrad_tn.hip).  Returns -1 when the layer is not this kernel's (the caller goes on to the single-tap
+// kernel), 100 / 101 for plan_only (accumulates / overwrites), 0 after a launch.
+int tv_wgrad_kx3_try(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias, hipStream_t s, bool plan_only, int accum) {
+    if (!g_kx3_enable) return -1;
+    auto log2_exact = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return ((1 << sh) == v) ? sh : -1; };
+    const int wsh = log2_exact(d->w_out), hwsh = log2_exact(d->h_out * d->w_out);
+    const long long M = (long long)d->batch * d->h_out * d->w_out;
+    const long long xbytes = M * d->ldx * 2, gbytes = M * d->ldo * 2;
+    const bool geo = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->up_shift == 0 && d->dil_mask == 0 &&
+                     d->h_in == d->h_out && d->w_in == d->w_out && wsh >= 6 && hwsh >= 6 &&
+                     xbytes + (long long)(d->w_in + 1) * d->ldx * 2 < (1ll << 31) && gbytes < (1ll << 31);
+    if (!geo) return -1;
+    const bool t192 = d->c_out % 192 == 0 && d->c_in % 96 == 0;
+    const bool t128 = d->c_out % 128 == 0 && d->c_in % 128 == 0;
+    if (!t192 && !t128) return -1;
+    Kx3Args a;
+    a.x = (const bf16*)x; a.gy = (const bf16*)gy; a.dw = dw; a.dbias = dbias;
+    a.M = (int)M; a.h = d->h_out; a.w = d->w_out; a.c_in = d->c_in; a.ldx = d->ldx; a.c_out = d->c_out; a.ldo = d->ldo;
+    a.tiles_ci = 1; a.chunk_px = 0; a.hw_shift = hwsh; a.w_shift = wsh; a.plain = 0;
+    a.xcd_order = 0; a.base = 1; a.ny = 1; a.accum = accum;
+    a.x_bytes = (unsigned)xbytes;
+    if (t192) return kx3_launch<192, 96, 4, 2>(a, s, plan_only);
+    return kx3_launch<128, 128, 2, 4>(a, s, plan_only);
+}

@@ -16,6 +16,9 @@
 // against an all-ones operand in the blocks that own (tap 0, ci tile 0).
 #include "common.h"
 
+// the kx-triple kernel for 3x3 / stride-1 layers (wgrad_kx3.hip); wgrad_impl asks it first
+int tv_wgrad_kx3_try(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias, hipStream_t s, bool plan_only, int accum);
+
 #ifndef TV_WGRAD_NO_PIPE
 #define TV_WGRAD_NO_PIPE 0
 #endif
@@ -474,323 +477,8 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 3x3 / stride 1 / pad 1 convolutions: the three kx taps of one ky share the staged tiles ("kx-triple").
-//
-// The single-tap kernel above streams gy and x once PER TAP: 9 x (|gy| + |x|) through L2 -> LDS per layer, 48 KiB of DMA per
-// 4.7 MFLOP K-step on the 192-wide tile -- its waves sit parked on the LDS-DMA (profiles/r01_gemm_kernels_pmc.json: MFMA
-// pipe 44 % busy, 40 % of wave-cycles waiting, HBM fetch 1.15x algorithmic: the L2 -> LDS fill rate is the bound, not HBM).
-// Here a block owns (co tile, ky, ci tile) and keeps THREE accumulator sets, one per kx.  A K-step stages 64 output pixels of
-// gy and the matching input rows of x ONCE, with one extra pixel on either side of every image-row segment; tap kx reads its
-// x fragments from the same LDS image shifted by kx rows.  DMA per FLOP drops 1.5x (192x64 tile) to 1.9x (128x128).
-//   x image: pixel r of the K-step (segment s = r / seg, seg = min(w, 64)) sits in tile row r + 2 s + 1; rows
-//   s (seg + 2) and s (seg + 2) + seg + 1 hold the left / right neighbour of the segment, or zeros at the image border
-//   (out-of-range DMA offset) -- which is exactly the zero padding of the convolution in x; padding in y = invalid rows.
-// ---------------------------------------------------------------------------------------------------------------
-#ifndef TV_WGRAD3_RING
-#define TV_WGRAD3_RING 4      // stages in the LDS ring of the kx-triple kernel (3 or 4): K-step t+RING-1 is issued during step t
-#endif
-template <int TG, int TX>
-__global__ __launch_bounds__(512, 1) void wgrad_tn3_kernel(const WgradArgs p) {
-    constexpr int NWN = 4, NW = 8, BKP = 64, XROWS = 72;  // 64 pixels + 2 halo rows for each of <= 4 segments
-    constexpr int RING = TV_WGRAD3_RING, LOOK = RING - 1;
-    constexpr int CG = TG / 8, CX = TX / 8;
-    constexpr int G_INSTR = BKP * CG / 64, X_INSTR = XROWS * CX / 64;
-    constexpr int G_IT = (G_INSTR + NW - 1) / NW, X_IT = (X_INSTR + NW - 1) / NW;
-    constexpr int G_BYTES = BKP * TG * 2, X_BYTES = XROWS * TX * 2, STAGE = G_BYTES + X_BYTES;
-    constexpr int WTG = TG / 2, WTX = TX / NWN, MF = WTG / 16, NF = WTX / 16;
-    static_assert(WTX % 16 == 0 && WTG % 16 == 0 && (XROWS * CX) % 64 == 0 && (BKP * CG) % 64 == 0, "tile shape");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / NWN, wn = wave % NWN;
-
-    int bx, chunk_id;
-    if (p.xcd_order) {   // all (co, ky, ci) tiles of a pixel chunk on one XCD (see wgrad_tn_kernel)
-        const int lin = blockIdx.x;
-        const int xcd = lin & 7, j = lin >> 3;
-        bx = j % p.base;
-        chunk_id = (j / p.base) * 8 + xcd;
-        if (chunk_id >= p.ny) return;
-    } else {
-        bx = blockIdx.x;
-        chunk_id = blockIdx.y;
-    }
-    const int ci_tile = bx % p.tiles_ci;
-    bx /= p.tiles_ci;
-    const int ky = bx % 3;
-    const int co_tile = bx / 3;
-    const int co0 = co_tile * TG, ci0 = ci_tile * TX;
-    const int p_begin = chunk_id * p.chunk_px;
-    const int p_end = min(p.M, p_begin + p.chunk_px);
-    const int nsteps = (p_end - p_begin + BKP - 1) / BKP;
-    if (nsteps <= 0) return;
-
-    const int w = p.w_out, hw = p.h_out * p.w_out;
-    const int seg_shift = p.w_shift < 6 ? p.w_shift : 6, seg = 1 << seg_shift, nseg = BKP >> seg_shift;
-    const int dty = ky - 1;
-
-    // ---- staging bookkeeping -------------------------------------------------------------------------------------------
-    int g_voff[G_IT];
-#pragma unroll
-    for (int it = 0; it < G_IT; ++it) {
-        const int id = (it * NW + wave) * 64 + lane;
-        const int r = id / CG, sl = id - r * CG;
-        const int col = co0 + tn_swz<TG>(sl, r) * 8;
-        g_voff[it] = (col < p.c_out) ? (r * p.ldo + col) * 2 : OOB_OFFSET;
-    }
-    int x_voff[X_IT], x_sg[X_IT], x_o[X_IT];
-#pragma unroll
-    for (int it = 0; it < X_IT; ++it) {
-        const int id = (it * NW + wave) * 64 + lane;
-        const int R = id / CX, sl = id - R * CX;
-        const int col = ci0 + tn_swz<TX>(sl, R) * 8;
-        const int sg = R / (seg + 2), o = R - sg * (seg + 2) - 1;     // -1 .. seg
-        x_sg[it] = (sg < nseg && col < p.c_in) ? sg : -1;
-        x_o[it] = o;
-        x_voff[it] = ((sg * seg + o + 1) * p.ldx + col) * 2;          // relative to x + (dty * w - 1) pixels
-    }
-    const long long dshift = ((long long)dty * p.w_in - 1) * p.ldx;     // elements
-    const bf16* xb = p.x + dshift;
-    const unsigned xb_bytes = (unsigned)((long long)p.x_bytes - dshift * 2);
-    const unsigned g_bytes = (unsigned)((long long)p_end * p.ldo * 2);   // rows >= p_end read as zeros
-
-    auto stage_issue = [&](int step, char* sbase) {
-        const int pz = p_begin + step * BKP;
-#pragma unroll
-        for (int it = 0; it < G_IT; ++it) {
-            if (G_INSTR % NW != 0 && it * NW + wave >= G_INSTR) break;
-            buffer_load_lds16(p.gy, g_bytes, sbase + (it * NW + wave) * 1024, g_voff[it], pz * p.ldo * 2);
-        }
-#pragma unroll
-        for (int it = 0; it < X_IT; ++it) {
-            if (X_INSTR % NW != 0 && it * NW + wave >= X_INSTR) break;
-            const int sg = x_sg[it], o = x_o[it];
-            const int p0 = pz + sg * seg;                           // first pixel of my segment
-            const int x0 = p0 & (w - 1);
-            const int uy = ((p0 & (hw - 1)) >> p.w_shift) + dty;
-            bool ok = sg >= 0 && (unsigned)uy < (unsigned)p.h_in;
-            ok = ok && (o >= 0 || x0 != 0) && (o < seg || x0 + seg < w);
-            buffer_load_lds16(xb, xb_bytes, sbase + G_BYTES + (it * NW + wave) * 1024, ok ? x_voff[it] : OOB_OFFSET, pz * p.ldx * 2);
-        }
-    };
-
-    // ---- fragment addressing (lane -> row 8g + 4h + q of a 32-pixel slice, columns base + 4pp .. +3) ----------------------
-    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    int a_off[2][MF];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int r = 8 * g + 4 * h + q;
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int col = wm * WTG + i * 16 + 4 * pp;
-            a_off[h][i] = r * (TG * 2) + tn_swz<TG>(col >> 3, r) * 16 + (pp & 1) * 8;
-        }
-    }
-    int b_chunk[NF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j) b_chunk[j] = (wn * WTX + j * 16 + 4 * pp) >> 3;
-
-    f32x4 acc[3][MF][NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int j = 0; j < NF; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // Bias gradient = column sums of gy.  The gy fragments are in registers anyway (lane L holds 8 pixels of output channel
-    // L & 15), so the owning waves add them up with vector ALU work in their LOAD phase (an extra MFMA against an all-ones
-    // operand, as in the single-tap kernel, puts branches and matrix work into the MFMA phase, which is the one that must not
-    // stretch).  Owners: the blocks of (ky = 1, ci tile 0); fragment i of a wave row belongs to the wave with wn == i % 4.
-    const bool do_bias = (p.dbias != nullptr) && ci_tile == 0 && ky == 1;
-    float bsum[(MF + NWN - 1) / NWN];
-#pragma unroll
-    for (int k = 0; k < (MF + NWN - 1) / NWN; ++k) bsum[k] = 0.f;
-
-    const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto join = [](bf16x4 lo, bf16x4 hi) { return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
-
-    // Wave-group ping-pong over a 3-deep ring of stages (the structure of conv3x3_halo_kernel's main loop, igemm_nt.hip):
-    // group 0 (waves 0-3) reads the fragments of K-step t and issues its share of step t+2's DMA in phase 2t and multiplies
-    // in phase 2t+1; group 1 (waves 4-7) runs one phase behind, so every SIMD always has one wave in its MFMA phase.
-    // Slot (t+2) % 3 held step t-1 (last read in phases 2t-2 / 2t-1): free in both load phases of step t.  A wave waits at the
-    // end of a load phase for everything it issued in EARLIER phases: step t+2 has landed one full step before it is read.
-    constexpr int SURE = G_INSTR / NW + X_INSTR / NW;      // pieces every wave issues per K-step (waves 0.. may issue one more)
-    bf16x4 alo[2][MF], ahi[2][MF], blo[2][3][NF], bhi[2][3][NF];
-    const int grp = wave >> 2;
-#pragma unroll
-    for (int st = 0; st < LOOK; ++st)
-        if (st < nsteps) stage_issue(st, smem + st * STAGE);
-    wait_vmcnt<0>();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    int slot = 0;
-    for (int t = 0; t < nsteps; ++t) {
-        // ---- load phase ----------------------------------------------------------------------------------------------------
-        __builtin_amdgcn_s_barrier();
-        const unsigned sa = smem_addr + slot * STAGE;
-        const unsigned sb = sa + G_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                alo[kk][i] = lds_tr16(sa + kk * 32 * (TG * 2) + a_off[0][i]);
-                ahi[kk][i] = lds_tr16(sa + kk * 32 * (TG * 2) + a_off[1][i]);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int rr = kk * 32 + 8 * g + 4 * h + q;            // pixel of the K-step
-                const int r0 = rr + 2 * (rr >> seg_shift);             // tile row of tap kx = 0
-#pragma unroll
-                for (int tp = 0; tp < 3; ++tp) {
-                    const int R = r0 + tp;
-#pragma unroll
-                    for (int j = 0; j < NF; ++j) {
-                        const unsigned a = sb + R * (TX * 2) + tn_swz<TX>(b_chunk[j], R) * 16 + (pp & 1) * 8;
-                        if (h == 0) blo[kk][tp][j] = lds_tr16(a);
-                        else bhi[kk][tp][j] = lds_tr16(a);
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const bool more = t + LOOK < nsteps;
-        if (more) {
-            const int fill = slot == 0 ? RING - 1 : slot - 1;          // (slot + LOOK) % RING
-            stage_issue(t + LOOK, smem + fill * STAGE);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (do_bias) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < MF; ++i)
-                    if (i % NWN == wn) {
-                        float a = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) a += (float)alo[kk][i][e] + (float)ahi[kk][i][e];
-                        bsum[i / NWN] += a;
-                    }
-        }
-        // the pieces of K-step t+1 (issued LOOK-1 load phases ago) have landed; younger ones may stay in flight
-        if (more) wait_vmcnt<(LOOK - 1) * SURE>();
-        else wait_vmcnt<0>();
-        // ---- MFMA phase ----------------------------------------------------------------------------------------------------
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                const bf16x8 af = join(alo[kk][i], ahi[kk][i]);
-#pragma unroll
-                for (int tp = 0; tp < 3; ++tp)
-#pragma unroll
-                    for (int j = 0; j < NF; ++j)
-                        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, join(blo[kk][tp][j], bhi[kk][tp][j]), acc[tp][i][j], 0, 0, 0);
-            }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        slot = slot == RING - 1 ? 0 : slot + 1;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-
-    // ---- fp32 atomics into dw[co][ky*3 + kx][ci]; D layout: row = (lane>>4)*4+reg (co), col = lane&15 (ci)
-    const size_t ldw = (size_t)9 * p.c_in;
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = co0 + wm * WTG + i * 16 + g * 4 + r;
-            if (co >= p.c_out) continue;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                float* rowp = p.dw + (size_t)co * ldw + (size_t)(ky * 3 + t) * p.c_in;
-#pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    const int ci = ci0 + wn * WTX + j * 16 + (lane & 15);
-                    if (ci < p.c_in) {
-                        if (p.plain && !p.accum) rowp[ci] = acc[t][i][j][r];
-                        else if (p.plain) rowp[ci] += acc[t][i][j][r];
-                        else atomicAdd(rowp + ci, acc[t][i][j][r]);
-                    }
-                }
-            }
-        }
-    }
-    if (do_bias) {   // lanes L, L+16, L+32, L+48 hold partial sums of the same output channel
-#pragma unroll
-        for (int i = 0; i < MF; ++i)
-            if (i % NWN == wn) {
-                float v = bsum[i / NWN];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                const int co = co0 + wm * WTG + i * 16 + (lane & 15);
-                if (lane < 16 && co < p.c_out) {
-                    if (p.plain && !p.accum) p.dbias[co] = v;
-                    else if (p.plain) p.dbias[co] += v;
-                    else atomicAdd(p.dbias + co, v);
-                }
-            }
-    }
-}
-
-// Measured on MI355X (tools/gemm_sweep.py, 64 images): the kx-triple kernel moves a third of the single-tap kernel's bytes from
-// L2 into LDS and runs the same time -- 2.87 vs 2.85 ms on the 192-channel 256x256 layers, 0.70 vs 0.71 ms at 1536@16, 0.80 vs
-// 0.77 ms at 384@64 (ring 4; ring 3: 3.0 ms; bias through MFMAs + branches in the MFMA phase: 3.25 ms).  The weight
-// gradient is therefore NOT bound by the L2 -> LDS fill rate, as the parked-wave counters of round 1 suggested, but by the
-// latency of the streamed operands behind a block barrier per 64 pixels (deeper rings help, tile shapes do not).  Kept as an
-// option (tv_set_wgrad_config(0, 0, -6)) and covered by tests; the single-tap kernel stays the default.
-int g_wgrad_triple = 0;
+// (The kx-triple kernel for 3x3 / stride-1 layers lives in wgrad_kx3.hip; wgrad_impl asks it first.)
 extern int g_wgrad_xcd, g_wgrad_blocks, g_wgrad_generic;
-
-template <int TG, int TX>
-int launch_triple(const WgradArgs& a0, hipStream_t s, bool plan_only) {
-    WgradArgs a = a0;
-    constexpr int BYTES = TV_WGRAD3_RING * (64 * TG + 72 * TX) * 2;
-    const int tiles_co = (a.c_out + TG - 1) / TG;
-    a.tiles_ci = (a.c_in + TX - 1) / TX;
-    const long long base = (long long)tiles_co * 3 * a.tiles_ci;
-    // split-K over pixel chunks: one block per CU; with the XCD-grouped order a chunk's `base` tiles share an XCD (32 CUs)
-    const double t_px = 2.0 * TG * TX * 3 * 256.0 / 1000e12;
-    const double tile_bytes = 4.0 * TG * TX * 3;
-    long long split = 1;
-    bool xcd = false;
-    double best = 1e30;
-    const long long smax = a.M / 512 > 0 ? a.M / 512 : 1;
-    for (long long sp = 1; sp <= smax && sp <= 4096; ++sp) {
-        const double rounds = (double)((long long)((base * sp + 255) / 256));
-        const double t = rounds * ((double)a.M / sp) * t_px + (sp > 1 ? base * sp * tile_bytes / 1.3e12 : 0.0);
-        if (t < best) { best = t; split = sp; xcd = false; }
-    }
-    if (g_wgrad_xcd && base <= 32) {
-        for (long long sp = 8; sp <= smax && sp <= 4096; sp += 8) {
-            const double rounds = (double)((long long)((base * (sp / 8) + 31) / 32));
-            const double t = rounds * ((double)a.M / sp) * (t_px * 0.85) + base * sp * tile_bytes / 1.3e12;
-            if (t < best) { best = t; split = sp; xcd = true; }
-        }
-    }
-    long long chunk = (a.M + split - 1) / split;
-    if (chunk < 512) chunk = 512;
-    chunk = (chunk + 63) / 64 * 64;
-    a.chunk_px = (int)chunk;
-    const int ny = (int)((a.M + chunk - 1) / chunk);
-    a.plain = (ny == 1) ? 1 : 0;
-    if (plan_only) return 100 + a.plain;
-    a.base = (int)base;
-    a.ny = ny;
-    a.xcd_order = (ny > 1 && xcd) ? 1 : 0;
-    dim3 grid((unsigned)base, (unsigned)ny);
-    if (a.xcd_order) grid = dim3((unsigned)(8 * base * ((ny + 7) / 8)), 1);
-    static TvPerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)wgrad_tn3_kernel<TG, TX>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-    }
-    hipLaunchKernelGGL((wgrad_tn3_kernel<TG, TX>), grid, dim3(512), BYTES, s, a);
-    return 0;
-}
 
 int g_wgrad_bkp = 0;     // 0 = heuristic (64), else 32 / 64 pixels per K-step
 int g_wgrad_blocks = 0;  // 0 = heuristic: target number of blocks for the split-K choice
@@ -916,7 +604,6 @@ extern "C" int tv_set_wgrad_stages(int stages) {   // 0 = heuristic, 2 / 3; +10:
 }
 
 extern "C" int tv_set_wgrad_config(int bkp, int waves, int blocks) {
-    g_wgrad_triple = (blocks == -6) ? 1 : 0;    // -6: 3x3 / stride-1 layers through the kx-triple kernel
     g_wgrad_generic = (blocks == -1) ? 1 : 0;
     g_wgrad_tile256 = (blocks == -2) ? 1 : ((blocks == -3 || blocks == -4) ? 2 : 0);
     g_wgrad_prefer192 = (blocks == -4) ? 1 : 0;
@@ -956,23 +643,11 @@ static int wgrad_impl(const tv_conv_desc* d, const void* x, const void* gy, floa
     a.xcd_order = 0; a.base = 1; a.ny = 1;
     a.accum = accum;
     hipStream_t s = (hipStream_t)stream;
-    {   // 3x3 / stride-1 / pad-1 on a power-of-two grid with both tensors below 2 GiB: the kx-triple kernel
-        auto log2_exact = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return ((1 << sh) == v) ? sh : -1; };
-        const int wsh = log2_exact(d->w_out), hwsh = log2_exact(d->h_out * d->w_out);
-        const long long xbytes = (long long)d->batch * d->h_in * d->w_in * d->ldx * 2, gbytes = M * d->ldo * 2;
-        const bool ok = g_wgrad_triple && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->up_shift == 0 && d->dil_mask == 0 &&
-                        d->h_in == d->h_out && d->w_in == d->w_out && wsh >= 4 && hwsh >= 8 && d->c_in % 64 == 0 && d->c_out % 64 == 0 &&
-                        xbytes + (long long)(d->w_in + 1) * d->ldx * 2 < (1ll << 31) && gbytes < (1ll << 31) && !g_wgrad_generic;
-        if (ok) {
-            a.w_shift = wsh;
-            a.hw_shift = hwsh;
-            a.x_bytes = (unsigned)xbytes;
-            int r;
-            if (d->c_out % 192 == 0 && d->c_out % 128 != 0) r = launch_triple<192, 64>(a, s, plan_only);
-            else if (d->c_out % 128 == 0 && d->c_in % 128 == 0) r = launch_triple<128, 128>(a, s, plan_only);
-            else r = launch_triple<64, 64>(a, s, plan_only);
+    if (!g_wgrad_generic && !g_wgrad_blocks) {   // 3x3 / stride-1 / pad-1 on image rows of >= 64 pixels: the kx-triple kernel (wgrad_kx3.hip)
+        const int r = tv_wgrad_kx3_try(d, x, gy, dw, dbias, s, plan_only, accum);
+        if (r >= 0) {
             if (plan_only) return r;
-            TV_CHECK_LAUNCH("tv_wgrad_tn");
+            TV_CHECK_LAUNCH("tv_wgrad_tn (kx3)");
             return TV_OK;
         }
     }

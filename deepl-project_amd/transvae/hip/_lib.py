@@ -145,6 +145,8 @@ def load():
         lib.tv_set_wgrad_stages.argtypes = [_I]
         lib.tv_set_wgrad_config.restype = _I
         lib.tv_set_wgrad_config.argtypes = [_I, _I, _I]
+        lib.tv_set_wgrad_kx3.restype = _I
+        lib.tv_set_wgrad_kx3.argtypes = [_I, _I, _I]
         _lib = lib
     return _lib
 

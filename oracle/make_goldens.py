@@ -434,6 +434,194 @@ def checkpoint():
     print("reference checkpoint written; losses", losses)
 
 
+def _large_model(R, gains=True):
+    import yaml
+    with open(REF + "/configs/transvae_large_f16d32.yaml") as f:
+        lcfg = yaml.safe_load(f)["model"]
+    model = R["TransVAE"](config=lcfg, variant="large", compression_ratio=16, latent_dim=32)
+    load_filled(model, "")
+    if gains:
+        with torch.no_grad():      # a log-variance head of standard deviation ~1 (oracle/filler.py: LARGE_GAINS)
+            for k, g in filler.LARGE_GAINS.items():
+                dict(model.named_parameters())[k].mul_(g)
+    return model
+
+
+def _sample(out, name, t, n=256):
+    flat = t.detach().flatten()
+    idx = torch.randperm(flat.numel(), generator=torch.Generator().manual_seed(zlib_crc(name)))[:n]
+    out[f"{name}.idx"] = idx.numpy()
+    out[f"{name}.val"] = flat[idx].float().numpy()
+    out[f"{name}.l2"] = np.asarray(float(flat.double().norm()))
+    out[f"{name}.std"] = np.asarray(float(flat.double().std()))
+
+
+LARGE512_GRAD_KEYS = [
+    "encoder.conv_in.weight", "encoder.stages.0.1.conv2.weight", "encoder.downsamples.1.main_path.2.weight",
+    "encoder.stages.2.0.attn.to_q.weight", "encoder.stages.2.2.attn.norm_k.bias", "encoder.stages.3.1.ffn.proj_in.weight",
+    "encoder.stages.4.5.ffn.conv.2.weight", "conv_mu.weight", "conv_logvar.weight", "decoder.conv_in.weight",
+    "decoder.stages.0.0.attn.proj.weight", "decoder.stages.2.2.attn.to_k.weight", "decoder.upsamples.2.dc_conv.weight",
+    "decoder.stages.4.2.conv2.weight", "decoder.norm_out.weight", "decoder.conv_out.weight",
+]
+
+
+def large512():
+    """BASELINE config 4's correctness leg with the backward: TransVAE-Large f16d32 on ONE 512 x 512 image (token grids
+    128^2 / 64^2 / 32^2), forward + backward through the REFERENCE on the CPU (fp32, filler weights + LARGE_GAINS): 256
+    sampled elements + norms of recon / mu / logvar and of 16 named gradients, and the deviation of the reference's own
+    bf16-autocast run on the same tensors.  The reference runs with ITS OWN per-block activation checkpointing
+    (R/transvae/models/encoder.py:97-99,117-118) so that the 31 TFLOP fit this container's 64 GB; the values are the same."""
+    import time
+    R = import_reference()
+    model = _large_model(R)
+    model.enable_gradient_checkpointing()
+    model.train()
+    x = filler.rand_input("large512.x", (1, 3, 512, 512))
+    eps = filler.randn_input("large512.eps", (1, 32, 32, 32))
+    orig = torch.randn_like
+
+    def run(autocast):
+        model.zero_grad()
+        torch.randn_like = lambda t, **kw: eps.to(t.dtype)
+        try:
+            if autocast:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    o = model(x, return_dict=True)
+                    loss = O.bench_loss(o["reconstruction"].float(), x, o["mu"].float(), o["logvar"].float())
+                    loss.backward()     # (inside the context: the checkpointed blocks re-run under the same autocast state anyway)
+            else:
+                o = model(x, return_dict=True)
+                loss = O.bench_loss(o["reconstruction"].float(), x, o["mu"].float(), o["logvar"].float())
+                loss.backward()
+        finally:
+            torch.randn_like = orig
+        params = dict(model.named_parameters())
+        return ({k: o[k].detach().float().clone() for k in ("reconstruction", "mu", "logvar")}, float(loss),
+                {k: params[k].grad.detach().clone() for k in LARGE512_GRAD_KEYS})
+    t0 = time.time()
+    o32, loss32, g32 = run(False)
+    print("large512 fp32 fwd+bwd %.1f s, loss %.5f" % (time.time() - t0, loss32), flush=True)
+    out = {"loss": np.asarray(loss32)}
+    for nm, key in (("recon", "reconstruction"), ("mu", "mu"), ("logvar", "logvar")):
+        _sample(out, nm, o32[key])
+    for k, g in g32.items():
+        _sample(out, "g:" + k, g)
+    np.savez_compressed(os.path.join(OUT, "large512_one_image.npz"), **out)
+    t0 = time.time()
+    o16, loss16, g16 = run(True)
+    print("large512 bf16-autocast fwd+bwd %.1f s" % (time.time() - t0), flush=True)
+    dev = {"loss_bf16": loss16}
+    for nm, key in (("recon", "reconstruction"), ("mu", "mu"), ("logvar", "logvar")):
+        dev[nm] = float((o16[key].double() - o32[key].double()).norm() / o32[key].double().norm())
+    for k in LARGE512_GRAD_KEYS:
+        n = float(g32[k].double().norm())
+        dev["g:" + k] = float((g16[k].double() - g32[k].double()).norm() / n) if n > 1e-12 else 0.0
+    print("reference bf16-autocast deviation at Large 512x512:", {k: round(v, 4) for k, v in dev.items()})
+    with open(os.path.join(OUT, "large512_ref_bf16_autocast.json"), "w") as f:
+        json.dump(dev, f, indent=0)
+
+
+def large1024():
+    """SURVEY 8f-3 widening (R/scripts/reproduce/test_rope_extrapolation.py:28-51 evaluates 256 / 512 / 1024): TransVAE-Large
+    f16d32 on ONE 1024 x 1024 image, forward only (no-grad inference path: encode -> z = mu + eps exp(logvar / 2) -> decode),
+    through the reference on the CPU: sampled values + norms, and the reference's own bf16-autocast deviation."""
+    import time
+    R = import_reference()
+    model = _large_model(R)
+    model.eval()
+    x = filler.rand_input("large1024.x", (1, 3, 1024, 1024))
+    eps = filler.randn_input("large1024.eps", (1, 32, 64, 64))
+    orig = torch.randn_like
+
+    def run(autocast):
+        torch.randn_like = lambda t, **kw: eps.to(t.dtype)
+        try:
+            with torch.no_grad():
+                if autocast:
+                    with torch.autocast("cpu", dtype=torch.bfloat16):
+                        o = model(x, return_dict=True)
+                else:
+                    o = model(x, return_dict=True)
+        finally:
+            torch.randn_like = orig
+        return {k: o[k].detach().float().clone() for k in ("reconstruction", "mu", "logvar")}
+    t0 = time.time()
+    o32 = run(False)
+    print("large1024 fp32 forward %.1f s" % (time.time() - t0), flush=True)
+    out = {}
+    for nm, key in (("recon", "reconstruction"), ("mu", "mu"), ("logvar", "logvar")):
+        _sample(out, nm, o32[key], 1024)
+    np.savez_compressed(os.path.join(OUT, "large1024_one_image.npz"), **out)
+    t0 = time.time()
+    o16 = run(True)
+    print("large1024 bf16-autocast forward %.1f s" % (time.time() - t0), flush=True)
+    dev = {nm: float((o16[key].double() - o32[key].double()).norm() / o32[key].double().norm())
+           for nm, key in (("recon", "reconstruction"), ("mu", "mu"), ("logvar", "logvar"))}
+    print("reference bf16-autocast deviation at Large 1024x1024:", dev)
+    with open(os.path.join(OUT, "large1024_ref_bf16_autocast.json"), "w") as f:
+        json.dump(dev, f, indent=0)
+
+
+def large_unit():
+    """The UNIT-GAIN Large fixture (no LARGE_GAINS: logvar of standard deviation ~5, |logvar| up to 20), 256 x 256, ONE image,
+    forward through the reference: sampled mu / logvar / z / recon, the decoder's output on the fp32 z, and the reference's
+    own bf16-autocast deviation split the way the tests assert it -- encoder outputs, and the DECODER ALONE on a fixed z
+    (decode(z32) under autocast vs fp32), i.e. without the exp(logvar / 2) amplification of the encoder's error."""
+    import time
+    R = import_reference()
+    model = _large_model(R, gains=False)
+    model.eval()
+    x = filler.rand_input("large.x", (1, 3, 256, 256))
+    eps = filler.randn_input("large.eps", (1, 32, 16, 16))
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **kw: eps.to(t.dtype)
+    try:
+        t0 = time.time()
+        with torch.no_grad():
+            o32 = model(x, return_dict=True)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                o16 = model(x, return_dict=True)
+                d16 = model.decode(o32["z"])
+        print("large unit-gain forward x2 + decode %.1f s" % (time.time() - t0), flush=True)
+    finally:
+        torch.randn_like = orig
+    out = {}
+    for nm, key in (("recon", "reconstruction"), ("mu", "mu"), ("logvar", "logvar"), ("z", "z")):
+        _sample(out, nm, o32[key], 1024)
+    out["logvar.absmax"] = np.asarray(float(o32["logvar"].abs().max()))
+    np.savez_compressed(os.path.join(OUT, "large_unit_one_image.npz"), **out)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    dev = {"recon": rel(o16["reconstruction"].float(), o32["reconstruction"]), "mu": rel(o16["mu"].float(), o32["mu"]),
+           "logvar": rel(o16["logvar"].float(), o32["logvar"]), "z": rel(o16["z"].float(), o32["z"]),
+           "decoder_alone": rel(d16.float(), o32["reconstruction"])}
+    print("reference bf16-autocast deviation, unit-gain Large:", dev)
+    with open(os.path.join(OUT, "large_unit_ref_bf16_autocast.json"), "w") as f:
+        json.dump(dev, f, indent=0)
+
+
+def schemas_more():
+    """State-dict schemas / parameter counts of the variants that have no YAML (huge, giant = BASELINE's "XL", large_f8d16),
+    built by the reference on the meta device from ITS OWN variant table (R/transvae/models/transvae.py:107-153), merged
+    into tests/golden/state_dict_schemas.json and param_counts.json."""
+    R = import_reference()
+    T = R["TransVAE"]
+    with open(os.path.join(OUT, "state_dict_schemas.json")) as f:
+        schemas = json.load(f)
+    for variant, f_, d in (("huge", 16, 32), ("giant", 16, 32), ("large", 8, 16)):
+        cfg = T._get_variant_config(None, variant, f_, d)
+        with torch.device("meta"):
+            m = T(config=cfg, variant=variant, compression_ratio=f_, latent_dim=d)
+        schemas[f"{variant}_f{f_}d{d}"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(OUT, "state_dict_schemas.json"), "w") as f:
+        json.dump(schemas, f)
+    counts = {k: int(sum(int(np.prod(s)) for kk, s in v.items() if not kk.endswith("inv_freq"))) for k, v in schemas.items()}
+    with open(os.path.join(OUT, "param_counts.json"), "w") as f:
+        json.dump(counts, f)
+    print("param counts", counts)
+
+
 def zlib_crc(k: str) -> int:
     import zlib
     return zlib.crc32(k.encode()) & 0x7FFFFFFF
@@ -446,5 +634,13 @@ if __name__ == "__main__":
         extra()
     elif "--checkpoint" in sys.argv:
         checkpoint()
+    elif "--large512" in sys.argv:   # ONE 512 x 512 image, forward + backward: ~10 min, < 40 GB (reference checkpointing on)
+        large512()
+    elif "--large1024" in sys.argv:  # ONE 1024 x 1024 image, forward only: ~20 min
+        large1024()
+    elif "--large-unit" in sys.argv:
+        large_unit()
+    elif "--schemas-more" in sys.argv:
+        schemas_more()
     else:
         main()

@@ -132,26 +132,27 @@ def test_conv_forward_backward(case, dma):
 
 
 WGRAD3_CASES = [
-    # (B, H, W, Cin, Cout): 3x3 / stride-1 weight gradient through the kx-triple kernel -- image-row segments of 16 / 32 /
-    # 64 pixels (W = 16, 32, >= 64), several segments per K-step, several K-steps, split-K chunks, all three tile shapes
-    (1, 16, 16, 192, 192),     # 192x64 tiles, four 16-pixel segments per K-step
-    (3, 16, 16, 64, 128),      # 64x64 tiles, batch 3
-    (2, 32, 32, 128, 256),     # 128x128 tiles, two 32-pixel segments per K-step
-    (1, 16, 64, 192, 192),     # non-square: one 64-pixel segment = one image row
-    (2, 32, 128, 64, 64),      # two K-steps per image row
-    (1, 64, 256, 128, 128),    # four K-steps per image row
-    (4, 64, 64, 192, 384),     # Cout 384 -> 128x... no: 384 % 128 == 0 and Cin 192 % 128 != 0 -> 64x64 tiles; split-K chunks
-    (5, 128, 128, 192, 192),   # 81 920 pixels: split over many chunks, XCD-grouped order, ragged last chunk
+    # (B, H, W, Cin, Cout, ring): 3x3 / stride-1 weight gradient through the kx-triple kernel (csrc/wgrad_kx3.hip: image rows of
+    # >= 64 pixels; one K-step = 64 pixels of one image row + its two neighbours) -- both tile shapes, one / several K-steps
+    # per image row, image borders in x and y, several images, split-K chunks, XCD-grouped order, both ring depths
+    (1, 16, 64, 192, 192, 0),     # 192 x 96 x 3 tiles: one K-step = one image row (both neighbours out of range)
+    (2, 8, 128, 96, 192, 3),      # two K-steps per image row, ring 3
+    (1, 64, 256, 128, 128, 0),    # 128 x 128 x 3 tiles, four K-steps per image row
+    (3, 16, 64, 128, 256, 3),     # 128-wide tiles, batch 3, ring 3
+    (4, 64, 64, 192, 384, 0),     # two co tiles x two ci tiles; split-K chunks
+    (5, 128, 128, 192, 192, 0),   # 81 920 pixels: split over many chunks, XCD-grouped order, ragged last chunk
+    (2, 64, 64, 384, 384, 0),     # the Conv-FFN 3x3 of stage 2 (384 = 2 x 192 = 4 x 96)
+    (1, 16, 32, 192, 192, 0),     # W < 64: not this kernel's -- falls through to the single-tap kernel
 ]
 
 
 @pytest.mark.parametrize("case", WGRAD3_CASES, ids=["x".join(map(str, c)) for c in WGRAD3_CASES])
 def test_wgrad_kx_triple(case):
     """tv_wgrad_tn on 3x3 / stride-1 layers (kx-triple kernel: the three kx taps share the staged tiles, x-padding from the
-    halo rows of each image-row segment; opt-in: tv_set_wgrad_config(0, 0, -6)) against fp32 PyTorch on the same
-    bf16-rounded operands, and against the default single-tap kernel on the same inputs."""
+    neighbour rows of each 64-pixel segment) against fp32 PyTorch on the same bf16-rounded operands, against the single-tap
+    kernel on the same inputs, and in accumulate mode (tv_wgrad_tn_acc)."""
     from transvae.hip import ops, _lib
-    B, H, W, Ci, Co = case
+    B, H, W, Ci, Co, ring = case
     g = torch.Generator().manual_seed(sum(case))
     x = r16(torch.randn(B, H, W, Ci, generator=g))
     gy = r16(torch.randn(B, H, W, Co, generator=g))
@@ -166,16 +167,22 @@ def test_wgrad_kx_triple(case):
     lib = _lib.load()
     outs = []
     for single in (False, True):
-        lib.tv_set_wgrad_config(0, 0, 0 if single else -6)
+        lib.tv_set_wgrad_kx3(0 if single else 1, ring, 0)
         try:
             dw, db = ops.conv_wgrad(geo, wd, xd, gd, True)
+            if not single:      # accumulate mode on top of a known tensor
+                dw2 = torch.full_like(dw, 0.5)
+                db2 = torch.full_like(db, -0.25)
+                ops.wgrad_acc(geo.fwd_desc(0), xd, gd, dw2, db2)
             torch.cuda.synchronize()
         finally:
-            lib.tv_set_wgrad_config(0, 0, 0)
+            lib.tv_set_wgrad_kx3(1, 0, 0)
         outs.append((dw.cpu(), db.cpu()))
         assert rel(dw, ref_dw) < 1e-2, ("single-tap" if single else "triple", rel(dw, ref_dw))
         assert rel(db, bn.grad) < 1e-2
     assert rel(outs[0][0], outs[1][0]) < 1e-4       # same bf16 products, fp32 sums in a different order
+    assert rel(outs[0][1], outs[1][1]) < 1e-4
+    assert rel(dw2 - 0.5, outs[0][0]) < 1e-4 and rel(db2 + 0.25, outs[0][1]) < 1e-4
 
 
 DERIV_CASES = [

@@ -396,19 +396,24 @@ def test_large_f16d32_256_full_size_properties_and_oracle():
     with torch.no_grad():
         r_ref, mu_ref, lv_ref = O.forward(x[:1], sd, cfg, eps[:1])
         z_ref = O.reparameterize(mu_ref, lv_ref, eps[:1])
-        e_z = l2rel(m.reparameterize(mu[:1], logvar[:1], ed[:1]), z_ref)
+        z_hip = m.reparameterize(mu[:1], logvar[:1], ed[:1])
+        e_z = l2rel(z_hip, z_ref)
         e_dec = l2rel(m.decode(z_ref.to(DEV)), r_ref)          # the decoder fed the ORACLE's z: its own error
+        d_ref_zhip = O.decode(z_hip.float().cpu(), sd, cfg)   # the ORACLE's decoder fed the path's z
     errs = (l2rel(recon[:1], r_ref), l2rel(mu[:1], mu_ref), l2rel(logvar[:1], lv_ref))
-    print("large f16d32 256x256 rel-L2 vs oracle (recon, mu, logvar):", errs, " z:", e_z, " decoder alone:", e_dec)
+    # exact split of the reconstruction error:  recon_hip - recon_ref = [dec_hip(z_hip) - dec_ref(z_hip)] + [dec_ref(z_hip) - dec_ref(z_ref)]
+    e_path = l2rel(recon[:1], d_ref_zhip)           # the path's own fault downstream of the sampling: must sit in the bf16 tier
+    e_prop = l2rel(d_ref_zhip, r_ref)               # the ORACLE's response to the encoder error in z (exp(logvar / 2) amplifies it): reported
+    print("large f16d32 256x256 rel-L2 vs oracle (recon, mu, logvar):", errs, " z:", e_z, " decoder alone (oracle z):", e_dec,
+          " dec_hip(z_hip) vs dec_ref(z_hip):", e_path, " dec_ref(z_hip) vs dec_ref(z_ref):", e_prop)
     # bf16 tier.  The yardstick (tests/golden/large_ref_bf16_autocast.json) is the reference's own bf16-autocast deviation
     # on the FILLER weights; these are the bench's weights, so it bounds what it can: the encoder outputs and the decoder by
-    # itself (measured on MI355X: mu 1.1e-2, logvar 1.1e-2 against 1.35e-2 / 1.58e-2).  The full reconstruction is downstream
-    # of z = mu + eps * exp(logvar / 2); for it the assertion is that its error is the propagated z error plus the decoder's
-    # own and nothing more (measured 1.4e-2 .. 1.8e-2 over builds that differ in one rounding).
+    # itself, on the oracle's z and on the path's own z (measured on MI355X: mu 1.1e-2, logvar 1.1e-2 against 1.35e-2 /
+    # 1.58e-2).  What the oracle itself makes of the 1.1e-2 logvar error (e_prop) is not the path's and is only reported.
     r16 = _large_ref16()
     assert errs[1] < max(1e-2, r16["mu"]) and errs[2] < max(1e-2, r16["logvar"]), errs
     assert e_dec < max(1e-2, r16["recon"]), e_dec
-    assert errs[0] < 1.5 * e_z + e_dec, (errs[0], e_z, e_dec)
+    assert e_path < max(1e-2, r16["recon"]), (e_path, e_prop)
 
 
 def test_large_f16d32_256_gradients_add_over_images():
@@ -593,16 +598,128 @@ def test_large_512_one_image_forward_against_oracle():
         z_ref = O.reparameterize(mu_ref, lv_ref, eps)
         z_hip = m.reparameterize(mu, logvar, eps.to(DEV))
         dec_alone = m.decode(z_ref.to(DEV))            # the decoder fed the ORACLE's z: its own error
+        d_ref_zhip = O.decode(z_hip.float().cpu(), sd, cfg)    # the ORACLE's decoder fed the path's z
     errs = (l2rel(recon, r_ref), l2rel(mu, mu_ref), l2rel(logvar, lv_ref))
     e_z, e_dec = l2rel(z_hip, z_ref), l2rel(dec_alone, r_ref)
-    print("large f16d32 512x512 rel-L2 vs oracle (recon, mu, logvar):", errs, " z:", e_z, " decoder alone:", e_dec)
-    r16 = _large_ref16()      # (the 256 x 256 yardstick: the reference's bf16 run at 512 x 512 takes minutes on the CPU)
-    # encoder outputs and the decoder by itself: the bf16 tier.  The full reconstruction is downstream of
-    # z = mu + eps * exp(logvar / 2), which multiplies the encoder's logvar error (measured: z 4.3e-2 from logvar 1.1e-2 with
-    # these weights); what is asserted for it is that the error is the propagated z error plus the decoder's own, nothing more.
+    e_path, e_prop = l2rel(recon, d_ref_zhip), l2rel(d_ref_zhip, r_ref)      # exact split (see the 256 x 256 test)
+    print("large f16d32 512x512 rel-L2 vs oracle (recon, mu, logvar):", errs, " z:", e_z, " decoder alone (oracle z):", e_dec,
+          " dec_hip(z_hip) vs dec_ref(z_hip):", e_path, " dec_ref(z_hip) vs dec_ref(z_ref):", e_prop)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large512_ref_bf16_autocast.json")) as f:
+        r16 = json.load(f)     # the reference's own bf16-autocast deviation at 512 x 512 (filler weights; these are the bench's)
+    # encoder outputs, the decoder on the oracle's z and the decoder on the path's own z: the bf16 tier.  What the ORACLE makes
+    # of the encoder's logvar error through z = mu + eps * exp(logvar / 2) (e_prop) is reported, not asserted.
     assert errs[1] < max(1e-2, r16["mu"]) and errs[2] < max(1e-2, r16["logvar"]), errs
     assert e_dec < max(1e-2, r16["recon"]), e_dec
-    assert errs[0] < 1.5 * e_z + e_dec, (errs[0], e_z, e_dec)
+    assert e_path < max(1e-2, r16["recon"]), (e_path, e_prop)
+
+
+def _sampled_err(t, g, name):
+    """rel-L2 of the elements of `t` at the golden's sampled indices against the reference's values, and the norm ratio."""
+    flat = t.detach().flatten().double().cpu()
+    got = flat[torch.as_tensor(g[f"{name}.idx"])].numpy()
+    ref = g[f"{name}.val"].astype(np.float64)
+    return float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), float(flat.norm()) / float(g[f"{name}.l2"])
+
+
+def test_large_512_one_image_forward_backward_against_reference_golden(golden_dir):
+    """BASELINE config 4's correctness leg WITH the backward (/root/reference README.md:192-203,
+    R/scripts/reproduce/test_rope_extrapolation.py:28-51): TransVAE-Large f16d32, ONE 512 x 512 image (token grids 128^2 /
+    64^2 / 32^2; N = 16 384 attention forward and backward inside the whole model), forward + backward of L1 + 1e-8 KL, against
+    values the REFERENCE computed on the CPU (tests/golden/large512_one_image.npz, minted by oracle/make_goldens.py --large512:
+    256 sampled elements and the norm of recon / mu / logvar and of 16 named gradients).  Yardstick: the reference's own
+    bf16-autocast deviation on the same tensors (large512_ref_bf16_autocast.json).  Sampled estimates of a rel-L2 error carry
+    ~ +-10 % of noise at 256 elements, hence 1.25 x on the outputs (full tensors: 1.0 x) and max(3e-2, 1.5 x) on gradients."""
+    g = golden(golden_dir, "large512_one_image.npz")
+    with open(os.path.join(golden_dir, "large512_ref_bf16_autocast.json")) as f:
+        ref16 = json.load(f)
+    m, sd, cfg = _large_filled()
+    m.train()
+    x = filler.rand_input("large512.x", (1, 3, 512, 512))
+    eps = filler.randn_input("large512.eps", (1, 32, 32, 32))
+    recon, mu, logvar = m(x.to(DEV), eps=eps.to(DEV))
+    loss = O.bench_loss(recon, x.to(DEV), mu, logvar)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 5e-3 * float(g["loss"]), (float(loss), float(g["loss"]))
+    rows = []
+    for nm, t in (("recon", recon), ("mu", mu), ("logvar", logvar)):
+        e, nr = _sampled_err(t, g, nm)
+        rows.append((nm, e, ref16[nm], nr))
+        assert e < max(1e-2, 1.25 * ref16[nm]), (nm, e, ref16[nm])
+        assert abs(nr - 1.0) < 2e-2, (nm, nr)
+    grads = dict(m.named_parameters())
+    keys = [k[2:-4] for k in g if k.startswith("g:") and k.endswith(".idx")]
+    assert len(keys) >= 10
+    for k in keys:
+        e, nr = _sampled_err(grads[k].grad, g, "g:" + k)
+        rows.append((k, e, ref16["g:" + k], nr))
+    print("large 512x512 vs reference-minted samples (ours / reference's own bf16 deviation / norm ratio):")
+    for nm, e, r, nr in rows:
+        print(f"   {nm:46s} {e:.4f} / {r:.4f} / {nr:.4f}")
+    for nm, e, r, nr in rows[3:]:
+        assert e < max(3e-2, 1.5 * r), (nm, e, r)
+        assert abs(nr - 1.0) < 5e-2, (nm, nr)
+
+
+def test_large_1024_one_image_forward_against_reference_golden(golden_dir):
+    """SURVEY 8f-3 widening (R/scripts/reproduce/test_rope_extrapolation.py:28-51 evaluates 256 / 512 / 1024): the whole
+    TransVAE-Large on ONE 1024 x 1024 image through the no-grad inference path (token grids 256^2 / 128^2 / 64^2: N = 65 536
+    attention, RoPE tables 4x beyond the training grid) against 1024 sampled values per output that the REFERENCE computed on
+    the CPU (tests/golden/large1024_one_image.npz, make_goldens.py --large1024), within the reference's own bf16 deviation."""
+    g = golden(golden_dir, "large1024_one_image.npz")
+    with open(os.path.join(golden_dir, "large1024_ref_bf16_autocast.json")) as f:
+        ref16 = json.load(f)
+    m, sd, cfg = _large_filled()
+    m.eval()
+    x = filler.rand_input("large1024.x", (1, 3, 1024, 1024))
+    eps = filler.randn_input("large1024.eps", (1, 32, 64, 64))
+    with torch.no_grad():
+        recon, mu, logvar = m(x.to(DEV), eps=eps.to(DEV))
+        recon2, _, _ = m(x.to(DEV), eps=eps.to(DEV))
+    assert torch.equal(recon, recon2) and torch.isfinite(recon).all() and recon.shape == x.shape
+    for nm, t in (("recon", recon), ("mu", mu), ("logvar", logvar)):
+        e, nr = _sampled_err(t, g, nm)
+        print(f"large 1024x1024 {nm}: rel-L2 on 1024 reference samples {e:.4f} (reference's own bf16 deviation {ref16[nm]:.4f}), norm ratio {nr:.4f}")
+        assert e < max(1e-2, 1.15 * ref16[nm]), (nm, e, ref16[nm])      # (1024 samples: ~ +-5 % on the estimate)
+        assert abs(nr - 1.0) < 2e-2, (nm, nr)
+
+
+def test_large_unit_gain_one_image_against_reference_golden(golden_dir):
+    """The UNIT-GAIN Large fixture (no LARGE_GAINS: logvar of standard deviation ~5, |logvar| up to ~20 -- the case in which
+    z = mu + eps * exp(logvar / 2) turns any encoder error into a reconstruction-error lottery).
+    Asserted here is exactly what is the path's own fault, each against the reference's own bf16-autocast deviation minted
+    on the same weights (tests/golden/large_unit_*, make_goldens.py --large-unit):
+      * mu, logvar on 1024 reference samples;
+      * the decoder on the path's OWN z:  dec_hip(z_hip) against dec_ref(z_hip) (the oracle's decoder fed the same z), full
+        tensors, against the reference's decoder-alone deviation (decode(z32) under autocast vs fp32);
+    reported, not asserted: recon against the reference (dominated by dec_ref(z_hip) - dec_ref(z_ref), the ORACLE's response
+    to the encoder's logvar error)."""
+    from transvae import TransVAE
+    g = golden(golden_dir, "large_unit_one_image.npz")
+    with open(os.path.join(golden_dir, "large_unit_ref_bf16_autocast.json")) as f:
+        ref16 = json.load(f)
+    cfg = O.variant_config("large", 16, 32)
+    sd = filler.fill_state_dict(O.state_dict_schema(cfg, 32))          # unit gain
+    m = TransVAE(variant="large", compression_ratio=16, latent_dim=32)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    x = filler.rand_input("large.x", (1, 3, 256, 256))
+    eps = filler.randn_input("large.eps", (1, 32, 16, 16))
+    with torch.no_grad():
+        recon, mu, logvar = m(x.to(DEV), eps=eps.to(DEV))
+        z_hip = m.reparameterize(mu, logvar, eps.to(DEV))
+        assert torch.equal(m.decode(z_hip), recon)
+        d_ref_zhip = O.decode(z_hip.float().cpu(), sd, cfg)
+    assert float(logvar.abs().max()) > 10.0        # this IS the hard case
+    e_mu, _ = _sampled_err(mu, g, "mu")
+    e_lv, _ = _sampled_err(logvar, g, "logvar")
+    e_z, _ = _sampled_err(z_hip, g, "z")
+    e_rec, _ = _sampled_err(recon, g, "recon")
+    e_path = l2rel(recon, d_ref_zhip)
+    print("large unit-gain: mu %.4f (ref bf16 %.4f)  logvar %.4f (%.4f)  z %.4f (%.4f)  dec_hip(z_hip) vs dec_ref(z_hip) %.4f "
+          "(ref decoder alone %.4f)  recon vs reference %.4f (ref bf16 %.4f; not asserted)" %
+          (e_mu, ref16["mu"], e_lv, ref16["logvar"], e_z, ref16["z"], e_path, ref16["decoder_alone"], e_rec, ref16["recon"]))
+    assert e_mu < max(1e-2, 1.15 * ref16["mu"]) and e_lv < max(1e-2, 1.15 * ref16["logvar"]), (e_mu, e_lv)
+    assert e_path < max(1e-2, 1.25 * ref16["decoder_alone"]), (e_path, ref16["decoder_alone"])
 
 
 def test_giant_f16d32_train_step_fits_288gb():
@@ -621,7 +738,12 @@ def test_giant_f16d32_train_step_fits_288gb():
     bench.init_scaled_(m, seed=0)
     m.train()
     n_params = m.get_num_params()["total"]
-    assert n_params == 4836751747 or n_params > 4.8e9, n_params
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(gdir, "param_counts.json")) as f:      # minted by the reference on the meta device (make_goldens.py --schemas-more)
+        assert n_params == json.load(f)["giant_f16d32"] == 4837304067, n_params
+    with open(os.path.join(gdir, "state_dict_schemas.json")) as f:
+        ref_schema = json.load(f)["giant_f16d32"]
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref_schema
     after_params = torch.cuda.memory_allocated()
     opt = FusedAdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0)
     after_opt = torch.cuda.memory_allocated()

@@ -141,6 +141,13 @@ def test_schema_matches_reference(golden_dir):
     with open(os.path.join(golden_dir, "param_counts.json")) as f:
         counts = json.load(f)
     assert counts["large_f16d32"] == 1049213827 and counts["tiny_f16d32"] == 81887427
+    # the variants without a YAML (huge, giant = BASELINE's "XL", large_f8d16): minted from the reference's own variant table on
+    # the meta device (oracle/make_goldens.py --schemas-more); SURVEY F5: giant is 4.837 B parameters as coded
+    for name, f_, d in (("huge", 16, 32), ("giant", 16, 32), ("large", 8, 16)):
+        key = f"{name}_f{f_}d{d}"
+        mine = O.state_dict_schema(O.variant_config(name, f_, d), d)
+        assert mine == {k: tuple(v) for k, v in ref[key].items()} and list(mine) == list(ref[key]), key
+    assert counts["giant_f16d32"] == 4837304067 and counts["huge_f16d32"] == 2488065859 and counts["large_f8d16"] == 1375456163
 
 
 def test_micro_model(golden_dir):
@@ -212,6 +219,24 @@ def test_oracle_large_forward_matches_reference_golden(golden_dir):
         loss = O.bench_loss(recon, x, mu, logvar)
     assert abs(float(loss) - float(g["loss"])) < 1e-5 * float(g["loss"])
     for nm, t in (("recon", recon), ("mu", mu), ("logvar", logvar)):
+        got = t.flatten().double()[g[f"{nm}.idx"]].numpy()
+        assert np.linalg.norm(got - g[f"{nm}.val"]) < 1e-4 * np.linalg.norm(g[f"{nm}.val"]), nm
+        assert abs(float(t.double().norm()) - float(g[f"{nm}.l2"])) < 1e-5 * float(g[f"{nm}.l2"]), nm
+
+
+def test_oracle_large_unit_gain_forward_matches_reference_golden(golden_dir):
+    """The unit-gain Large fixture (no LARGE_GAINS: |logvar| up to ~20; tests/golden/large_unit_one_image.npz from
+    `oracle/make_goldens.py --large-unit`): the oracle's forward against 1024 reference samples per tensor, z included."""
+    g = dict(np.load(os.path.join(golden_dir, "large_unit_one_image.npz")))
+    cfg = O.variant_config("large", 16, 32)
+    sd = filler.fill_state_dict(O.state_dict_schema(cfg, 32))
+    x = filler.rand_input("large.x", (1, 3, 256, 256))
+    eps = filler.randn_input("large.eps", (1, 32, 16, 16))
+    with torch.no_grad():
+        recon, mu, logvar = O.forward(x, sd, cfg, eps)
+        z = O.reparameterize(mu, logvar, eps)
+    assert float(logvar.abs().max()) > 10.0 and abs(float(logvar.abs().max()) - float(g["logvar.absmax"])) < 1e-3
+    for nm, t in (("recon", recon), ("mu", mu), ("logvar", logvar), ("z", z)):
         got = t.flatten().double()[g[f"{nm}.idx"]].numpy()
         assert np.linalg.norm(got - g[f"{nm}.val"]) < 1e-4 * np.linalg.norm(g[f"{nm}.val"]), nm
         assert abs(float(t.double().norm()) - float(g[f"{nm}.l2"])) < 1e-5 * float(g[f"{nm}.l2"]), nm
