@@ -76,7 +76,26 @@ constexpr int kx_xrows(int cx) {   // >= 66 rows and a whole number of 1 KiB DMA
     return r;
 }
 
-template <int TG, int TX, int NWM, int NWN, int RING>
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Schedule variants (VAR), all bit-identical in their results:
+//   0  every fragment read and every LDS-DMA piece in the load phase, K-step t + RING - 1 issued during step t
+//   1  the reads of the second 32-pixel half threaded between the MFMAs of the first, all DMA pieces in the MFMA phase
+//   2  ... reads threaded, lookahead RING - 2, gy pieces in the load phase, x pieces in the MFMA phase
+//   3  ... reads threaded, lookahead RING - 2, all pieces in the load phase
+//   4  all reads in the load phase, gy pieces in the load phase, x pieces in the MFMA phase
+// Hazard rule behind the lookahead: a wave's MFMA phase t runs beside the other group's load phase t (group 0) or t + 1
+// (group 1).  Reads threaded into the MFMA phase make a group read K-step t while the other group is already in load phase
+// t + 1, so a piece issued in a LOAD phase may then only overwrite the slot of step t - 2 (lookahead RING - 2); pieces issued
+// in an MFMA phase may always overwrite the slot of step t - 1.
+template <int TG, int TX, int NWM, int NWN, int RING, int VAR>
 __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     constexpr int NW = 8, BKP = 64;
     static_assert(NWM * NWN == NW, "8 waves");
@@ -85,14 +104,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     constexpr int G_PIECES = BKP * CG / 64;                    // 1 KiB pieces of the gy tile
     constexpr int X_PIECES = (66 * CX + 63) / 64;              // ... of the 66 used rows of the x tile
     static_assert(G_PIECES % NW == 0, "gy pieces divide over the waves");
-    constexpr int G_IT = G_PIECES / NW, X_IT = (X_PIECES + NW - 1) / NW;
+    constexpr int G_IT = G_PIECES / NW, X_IT = (X_PIECES + NW - 1) / NW, P_IT = G_IT + X_IT;
+    constexpr int XR = X_PIECES % NW;                          // waves below XR issue X_IT x pieces, the others X_IT - 1 (XR != 0)
     constexpr int G_BYTES = BKP * TG * 2, X_BYTES = XROWS * TX * 2;
     constexpr int X_REGION = RING * G_BYTES;
     static_assert(RING * (G_BYTES + X_BYTES) <= 160 * 1024, "LDS");
     constexpr int WTG = TG / NWM, WTX = TX / NWN, MF = WTG / 16, NF = WTX / 16;
     static_assert(WTG % 16 == 0 && WTX % 16 == 0, "wave tile");
-    constexpr int LOOK = RING - 1;
-    constexpr int SURE = G_IT + X_PIECES / NW;                 // pieces EVERY wave issues per K-step (low waves may issue one more)
+    constexpr bool RD_SPLIT = VAR == 1 || VAR == 2 || VAR == 3;
+    constexpr int LOOK = (VAR == 2 || VAR == 3) ? RING - 2 : RING - 1;
+    constexpr int IT_SPLIT = VAR == 1 ? 0 : ((VAR == 2 || VAR == 4) ? G_IT : P_IT);   // piece iterations [0, IT_SPLIT) go in the load phase
+    static_assert(LOOK >= 2, "the wait at the end of load phase t covers K-step t + 1");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -143,23 +165,28 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     const unsigned xb_bytes = (unsigned)((long long)p.x_bytes - dshift * 2);
     const unsigned g_bytes = (unsigned)((long long)p_end * p.ldo * 2);
 
-    auto stage_issue = [&](int step, int slot) {
+    // piece iteration IT of K-step `step` into ring slot `slot`: IT < G_IT a gy piece, else an x piece
+    auto x_have = [&](int step) {   // one scalar mask per step against one per-lane bit: no divergent control flow around the DMA issue
         const int pz = p_begin + step * BKP;
-        char* gdst = smem + slot * G_BYTES;
-        char* xdst = smem + X_REGION + slot * X_BYTES;
-#pragma unroll
-        for (int it = 0; it < G_IT; ++it)
-            buffer_load_lds16(p.gy, g_bytes, gdst + (it * NW + wave) * 1024, g_voff[it], pz * p.ldo * 2);
         const int x0 = pz & (w - 1);
         const int uy = ((pz & (hw - 1)) >> p.w_shift) + dty;
-        const bool row_ok = (unsigned)uy < (unsigned)p.h;
-        // (one scalar mask per step against one per-lane bit: no divergent control flow around the DMA issue)
-        const int have = row_ok ? (1 | (x0 != 0 ? 2 : 0) | (x0 + BKP < w ? 4 : 0)) : 0;
-#pragma unroll
-        for (int it = 0; it < X_IT; ++it) {
-            if (X_PIECES % NW != 0 && it * NW + wave >= X_PIECES) break;
-            buffer_load_lds16(xb, xb_bytes, xdst + (it * NW + wave) * 1024, (x_need[it] & have) ? x_voff[it] : OOB_OFFSET, pz * p.ldx * 2);
+        return ((unsigned)uy < (unsigned)p.h) ? (1 | (x0 != 0 ? 2 : 0) | (x0 + BKP < w ? 4 : 0)) : 0;
+    };
+    auto issue_piece = [&](auto it_c, int step, int slot, int have) {
+        constexpr int IT = decltype(it_c)::value;
+        const int pz = p_begin + step * BKP;
+        if constexpr (IT < G_IT) {
+            buffer_load_lds16(p.gy, g_bytes, smem + slot * G_BYTES + (IT * NW + wave) * 1024, g_voff[IT], pz * p.ldo * 2);
+        } else {
+            constexpr int XI = IT - G_IT;
+            if (XR != 0 && XI == X_IT - 1 && wave >= XR) return;
+            buffer_load_lds16(xb, xb_bytes, smem + X_REGION + slot * X_BYTES + (XI * NW + wave) * 1024,
+                              (x_need[XI] & have) ? x_voff[XI] : OOB_OFFSET, pz * p.ldx * 2);
         }
+    };
+    auto stage_issue = [&](int step, int slot) {
+        const int have = x_have(step);
+        static_for<P_IT>([&](auto it_c) { issue_piece(it_c, step, slot, have); });
     };
 
     // ---- fragment addressing: lane (g = lane>>4, q = (lane>>2)&3, pp = lane&3) supplies row 8g + 4h + q (+ 32 kk), columns
@@ -203,9 +230,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
             for (int j = 0; j < NF; ++j) acc[tp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // bias gradient = column sums of gy: the gy fragments are in registers anyway (lane L holds 8 pixels of output channel
-    // L & 15), the owning waves add them up with vector ALU work in their LOAD phase.  Owners: the blocks of (ky = 1, ci tile 0);
-    // fragment i of a wave row belongs to the wave with wn == i % NWN.
-    const bool do_bias = (p.dbias != nullptr) && ci_tile == 0 && ky == 1;
+    // L & 15), the owning waves add them up with vector ALU work in their LOAD phase; fragment i of a wave row belongs to the
+    // wave with wn == i % NWN.  The 3 x tiles_ci blocks of a pixel chunk that share a co tile all hold the same gy fragments:
+    // they take the K-steps in turn (block `mine` sums steps mine, mine + nshare, ...), so no block carries the extra ~80
+    // vector instructions in every step -- with ONE owner block per co tile (ky = 1, ci tile 0) that block, and with it
+    // the launch (one block per CU), ran 25-30 % longer than the bias-free kernel.  Every block ADDS its share into dbias
+    // with atomics (single-chunk launches too): the caller passes a zeroed dbias or one that holds a running sum.
+    const bool do_bias = p.dbias != nullptr;
+    const int nshare = 3 * p.tiles_ci;
+    int bias_ctr = ky * p.tiles_ci + ci_tile;     // steps until this block's next turn
+    bool own = false, own_prev = false;
     constexpr int NB = (MF + NWN - 1) / NWN;
     float bsum[NB];
 #pragma unroll
@@ -214,6 +248,42 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     auto join = [](bf16x4 lo, bf16x4 hi) { return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
     bf16x4 alo[2][MF], ahi[2][MF], blo[2][3][NF], bhi[2][3][NF];
     const int grp = wave >> 2;
+
+    // read number R of the NR = 2 MF + 6 NF transposing reads of 32-pixel half KK of ring slot SLOT
+    constexpr int NR = 2 * MF + 6 * NF, NM = 3 * MF * NF;
+    auto frag_read = [&](auto kk_c, auto r_c, auto slot_c) {
+        constexpr int KK = decltype(kk_c)::value, R = decltype(r_c)::value, SLOT = decltype(slot_c)::value;
+        if constexpr (R < 2 * MF) {
+            constexpr int i = R / 2, h = R % 2;
+            constexpr int OFF = ((A_TWO && SLOT >= 2) ? (SLOT - 2) * G_BYTES : SLOT * G_BYTES) + KK * 32 * TG * 2 + h * 4 * TG * 2;
+            const unsigned ab = (A_TWO && SLOT >= 2) ? a_base2[i] : a_base[i];
+            if constexpr (h == 0) alo[KK][i] = lds_tr16<OFF>(ab);
+            else ahi[KK][i] = lds_tr16<OFF>(ab);
+        } else {
+            constexpr int rr = R - 2 * MF, tp = rr / (2 * NF), j = (rr / 2) % NF, h = rr % 2;
+            constexpr int OFF = SLOT * X_BYTES + KK * 32 * TX * 2;
+            if constexpr (h == 0) blo[KK][tp][j] = lds_tr16<OFF>(b_base[0][tp][j]);
+            else bhi[KK][tp][j] = lds_tr16<OFF>(b_base[1][tp][j]);
+        }
+    };
+    auto mfma_one = [&](auto kk_c, auto m_c) {
+        constexpr int KK = decltype(kk_c)::value, M = decltype(m_c)::value;
+        constexpr int i = M / (3 * NF), tp = (M / NF) % 3, j = M % NF;
+        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(alo[KK][i], ahi[KK][i]), join(blo[KK][tp][j], bhi[KK][tp][j]), acc[tp][i][j], 0, 0, 0);
+    };
+    auto bias_add = [&](auto kk_c) {
+        constexpr int KK = decltype(kk_c)::value;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+            if (i % NWN == wn) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a += (float)alo[KK][i][e] + (float)ahi[KK][i][e];
+                bsum[i / NWN] += a;
+            }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
 
 #pragma unroll
     for (int st = 0; st < LOOK; ++st)
@@ -224,71 +294,86 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     // one K-step with the ring slot as a compile-time constant
     auto step = [&](int t, auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
-        constexpr int A_OFF = (A_TWO && SLOT >= 2) ? (SLOT - 2) * G_BYTES : SLOT * G_BYTES;
+        constexpr int FILL = (SLOT + LOOK) % RING;
+        const bool more = t + LOOK < nsteps;
+        own_prev = own;
+        own = do_bias && bias_ctr == 0;
+        bias_ctr = bias_ctr == 0 ? nshare - 1 : bias_ctr - 1;
         // ---- load phase ----------------------------------------------------------------------------------------------------
         __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                const unsigned ab = (A_TWO && SLOT >= 2) ? a_base2[i] : a_base[i];
-                if (kk == 0) {
-                    alo[0][i] = lds_tr16<A_OFF>(ab);
-                    ahi[0][i] = lds_tr16<A_OFF + 4 * TG * 2>(ab);
-                } else {
-                    alo[1][i] = lds_tr16<A_OFF + 32 * TG * 2>(ab);
-                    ahi[1][i] = lds_tr16<A_OFF + 32 * TG * 2 + 4 * TG * 2>(ab);
-                }
-            }
-#pragma unroll
-            for (int tp = 0; tp < 3; ++tp)
-#pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    if (kk == 0) {
-                        blo[0][tp][j] = lds_tr16<SLOT * X_BYTES>(b_base[0][tp][j]);
-                        bhi[0][tp][j] = lds_tr16<SLOT * X_BYTES>(b_base[1][tp][j]);
-                    } else {
-                        blo[1][tp][j] = lds_tr16<SLOT * X_BYTES + 32 * TX * 2>(b_base[0][tp][j]);
-                        bhi[1][tp][j] = lds_tr16<SLOT * X_BYTES + 32 * TX * 2>(b_base[1][tp][j]);
-                    }
-                }
+        if constexpr (RD_SPLIT) {   // (the second half's gy fragments of the previous step are still in registers: their bias sums first)
+            if (own_prev) bias_add(I1{});
+            __builtin_amdgcn_sched_barrier(0);
         }
+        static_for<NR>([&](auto r_c) { frag_read(I0{}, r_c, slot_c); });
+        if constexpr (!RD_SPLIT) static_for<NR>([&](auto r_c) { frag_read(I1{}, r_c, slot_c); });
         __builtin_amdgcn_sched_barrier(0);
-        const bool more = t + LOOK < nsteps;
-        if (more) stage_issue(t + LOOK, (SLOT + LOOK) % RING);
+        const int have = more ? x_have(t + LOOK) : 0;
+        if (more) static_for<IT_SPLIT>([&](auto it_c) { issue_piece(it_c, t + LOOK, FILL, have); });
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (do_bias) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < MF; ++i)
-                    if (i % NWN == wn) {
-                        float a = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) a += (float)alo[kk][i][e] + (float)ahi[kk][i][e];
-                        bsum[i / NWN] += a;
-                    }
+        if (own) {
+            bias_add(I0{});
+            if constexpr (!RD_SPLIT) bias_add(I1{});
         }
-        // the pieces of K-step t+1 (issued LOOK-1 load phases ago) have landed; younger ones may stay in flight
-        if (!more) wait_vm<0>();
-        else if (X_PIECES % NW != 0 && wave < X_PIECES % NW) wait_vm<(LOOK - 1) * (SURE + 1)>();
-        else wait_vm<(LOOK - 1) * SURE>();
+        // every piece of K-step t + 1 has landed; younger ones stay in flight: (LOOK - 2) whole steps + what this phase issued
+        {
+            constexpr int NLG = IT_SPLIT < G_IT ? IT_SPLIT : G_IT;                      // gy pieces issued in a load phase
+            constexpr int NLX = IT_SPLIT > G_IT ? IT_SPLIT - G_IT : 0;                  // x piece iterations issued in a load phase
+            constexpr int P_HI = G_IT + X_IT, P_LO = G_IT + X_IT - (XR != 0 ? 1 : 0);   // pieces per step: waves below XR / the others
+            constexpr int L_HI = NLG + NLX, L_LO = NLG + NLX - ((XR != 0 && NLX == X_IT) ? 1 : 0);
+            if (!more) wait_vm<0>();
+            else if (XR != 0 && wave < XR) wait_vm<(LOOK - 2) * P_HI + L_HI>();
+            else wait_vm<(LOOK - 2) * P_LO + L_LO>();
+        }
         // ---- MFMA phase ----------------------------------------------------------------------------------------------------
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                const bf16x8 af = join(alo[kk][i], ahi[kk][i]);
-#pragma unroll
-                for (int tp = 0; tp < 3; ++tp)
-#pragma unroll
-                    for (int j = 0; j < NF; ++j)
-                        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, join(blo[kk][tp][j], bhi[kk][tp][j]), acc[tp][i][j], 0, 0, 0);
+        if constexpr (!RD_SPLIT && IT_SPLIT == P_IT) {
+            static_for<NM>([&](auto m_c) { mfma_one(I0{}, m_c); });
+            static_for<NM>([&](auto m_c) { mfma_one(I1{}, m_c); });
+        } else {
+            // hand schedule: the NR reads of the second half after the first NR MFMAs, one each; the remaining DMA pieces
+            // spread over the phase, each after a whole MFMA
+            constexpr int NP = P_IT - IT_SPLIT;                   // piece iterations issued in this phase
+            static_for<NM>([&](auto m_c) {
+                constexpr int M = decltype(m_c)::value;
+                mfma_one(I0{}, m_c);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (RD_SPLIT) {
+                    constexpr int r0 = M * NR / NM, r1 = (M + 1) * NR / NM;
+                    static_for<r1 - r0>([&](auto d_c) { frag_read(I1{}, std::integral_constant<int, r0 + decltype(d_c)::value>{}, slot_c); });
+                }
+                if constexpr (NP > 0) {   // piece k after MFMA (2 k + 1) NM / (2 NP) of the 2 NM in this phase, first half only when it fits
+                    static_for<NP>([&](auto k_c) {
+                        constexpr int K = decltype(k_c)::value;
+                        if constexpr ((2 * K + 1) * 2 * NM / (2 * NP) == M) {
+                            if (more) issue_piece(std::integral_constant<int, IT_SPLIT + K>{}, t + LOOK, FILL, have);
+                        }
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (RD_SPLIT) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
             }
+            static_for<NM>([&](auto m_c) {
+                constexpr int M = decltype(m_c)::value + NM;
+                mfma_one(I1{}, m_c);
+                if constexpr (NP > 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<NP>([&](auto k_c) {
+                        constexpr int K = decltype(k_c)::value;
+                        if constexpr ((2 * K + 1) * 2 * NM / (2 * NP) == M) {
+                            if (more) issue_piece(std::integral_constant<int, IT_SPLIT + K>{}, t + LOOK, FILL, have);
+                        }
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -300,6 +385,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
         if constexpr (RING == 4) {
             if (t + 3 < nsteps) step(t + 3, std::integral_constant<int, 3 % RING>{});
         }
+    }
+    if constexpr (RD_SPLIT) {
+        if (own) bias_add(I1{});
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
 
@@ -331,21 +419,28 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
                 const int co = co0 + wm * WTG + i * 16 + (lane & 15);
-                if (lane < 16) {
-                    if (p.plain && !p.accum) p.dbias[co] = v;
-                    else if (p.plain) p.dbias[co] += v;
-                    else atomicAdd(p.dbias + co, v);
-                }
+                if (lane < 16) atomicAdd(p.dbias + co, v);
             }
     }
 }
 
 int g_kx3_ring = 0;     // 0 = default (4 where it fits), 3 / 4: A/B
+int g_kx3_var = -1;     // schedule variant (see the kernel); -1 = default (4 with a ring of 4)
 int g_kx3_blocks = 0;   // 0 = cost model, else target number of blocks
+
+template <int TG, int TX, int NWM, int NWN, int RING, int VAR>
+int kx3_launch_v(const Kx3Args& a, dim3 grid, hipStream_t s) {
+    constexpr int BYTES = RING * (64 * TG * 2 + kx_xrows(TX / 8) * TX * 2);
+    static TvPerDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute((const void*)wgrad_kx3_kernel<TG, TX, NWM, NWN, RING, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    }
+    hipLaunchKernelGGL((wgrad_kx3_kernel<TG, TX, NWM, NWN, RING, VAR>), grid, dim3(512), BYTES, s, a);
+    return 0;
+}
 
 template <int TG, int TX, int NWM, int NWN, int RING>
 int kx3_launch_r(Kx3Args a, hipStream_t s, bool plan_only) {
-    constexpr int BYTES = RING * (64 * TG * 2 + kx_xrows(TX / 8) * TX * 2);
     const int tiles_co = a.c_out / TG;
     a.tiles_ci = a.c_in / TX;
     const long long base = (long long)tiles_co * 3 * a.tiles_ci;
@@ -386,12 +481,16 @@ int kx3_launch_r(Kx3Args a, hipStream_t s, bool plan_only) {
     a.xcd_order = (ny > 1 && xcd) ? 1 : 0;
     dim3 grid((unsigned)base, (unsigned)ny);
     if (a.xcd_order) grid = dim3((unsigned)(8 * base * ((ny + 7) / 8)), 1);
-    static TvPerDeviceOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kx3_kernel<TG, TX, NWM, NWN, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    if constexpr (RING == 4) {   // (the lookahead RING - 2 variants need a ring of 4)
+        switch (g_kx3_var < 0 ? 4 : g_kx3_var) {
+            case 1: return kx3_launch_v<TG, TX, NWM, NWN, RING, 1>(a, grid, s);
+            case 2: return kx3_launch_v<TG, TX, NWM, NWN, RING, 2>(a, grid, s);
+            case 3: return kx3_launch_v<TG, TX, NWM, NWN, RING, 3>(a, grid, s);
+            case 4: return kx3_launch_v<TG, TX, NWM, NWN, RING, 4>(a, grid, s);
+            default: break;
+        }
     }
-    hipLaunchKernelGGL((wgrad_kx3_kernel<TG, TX, NWM, NWN, RING>), grid, dim3(512), BYTES, s, a);
-    return 0;
+    return kx3_launch_v<TG, TX, NWM, NWN, RING, 0>(a, grid, s);
 }
 
 template <int TG, int TX, int NWM, int NWN>
@@ -408,9 +507,10 @@ int kx3_launch(const Kx3Args& a, hipStream_t s, bool plan_only) {
 // A/B hooks (tools/, tests): ring depth (0 = default, 3, 4), block target for the split-K choice (0 = cost model)
 extern "C" int tv_set_wgrad_kx3(int enable, int ring, int blocks);
 int g_kx3_enable = 1;
-extern "C" int tv_set_wgrad_kx3(int enable, int ring, int blocks) {
+extern "C" int tv_set_wgrad_kx3(int enable, int ring, int blocks) {   // ring = depth + 10 x schedule variant
     g_kx3_enable = enable;
-    g_kx3_ring = ring;
+    g_kx3_ring = ring % 10;
+    g_kx3_var = ring >= 10 ? ring / 10 : (ring == 0 ? -1 : 0);     // a bare ring depth selects schedule 0 (A/B); 0 = all defaults
     g_kx3_blocks = blocks;
     return 0;
 }

@@ -279,12 +279,29 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
     //  owners now add the gy fragments up with vector ALU work -- lane L of an A fragment holds 8 pixels of output channel
     //  L & 15 -- behind ONE wave-uniform branch per sub-step.  Owners: the blocks of (tap 0, ci tile 0); fragment i of a
     //  wave row belongs to the wave with wn == i % NWN.)
-    const bool do_bias = (p.dbias != nullptr) && ci_tile == 0 && tap == 0;
+    // (round 3: with ONE owner block per co tile that block carried the sums in every K-step and ran ~25 % longer than the
+    //  others -- and with one block per CU the launch with it: 2.75 -> 3.39 ms on the 192-channel 3x3 layers.  The taps x
+    //  tiles_ci blocks of a pixel chunk that share a co tile hold the same gy fragments, so they take the K-steps in turn.
+    //  Every block therefore ADDS its share into dbias with atomics, single-chunk launches included: the caller passes a
+    //  zeroed dbias, or one that holds a running sum.)
+#ifdef TV_BIAS_ONE_OWNER      // (A/B build: the round-2 scheme)
+    const bool one_owner = true;
+#else
+    const bool one_owner = false;
+#endif
+    const bool do_bias = (p.dbias != nullptr) && (!one_owner || (ci_tile == 0 && tap == 0));
+    const int nshare = one_owner ? 1 : taps * p.tiles_ci;
+    int bias_ctr = one_owner ? 0 : tap * p.tiles_ci + ci_tile;     // K-steps until this block's next turn
+    bool bias_now = false;
+    auto bias_turn = [&]() {     // call once per K-step, before its fragments are summed
+        bias_now = do_bias && bias_ctr == 0;
+        bias_ctr = bias_ctr == 0 ? nshare - 1 : bias_ctr - 1;
+    };
     float bsum[(MF + NWN - 1) / NWN];
 #pragma unroll
     for (int k = 0; k < (MF + NWN - 1) / NWN; ++k) bsum[k] = 0.f;
     auto bias_add = [&](const bf16x4 (&alo)[MF], const bf16x4 (&ahi)[MF]) {
-        if (!do_bias) return;
+        if (!bias_now) return;
 #pragma unroll
         for (int i = 0; i < MF; ++i)
             if (i % NWN == wn) {
@@ -410,6 +427,7 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
                 read_sub(u + 1, nalo, nahi, nblo, nbhi);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (u % KH == 0) bias_turn();
             mfma_sub(calo, cahi, cblo, cbhi);
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -436,6 +454,7 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (t + 1 < nsteps) stage_issue(t + 1, smem + ((t + 1) & 1) * STAGE);
+            bias_turn();
             compute(t & 1);
         }
     }
@@ -468,11 +487,7 @@ __global__ __launch_bounds__(128 * NWN, (wgrad_min_waves<TG, TX, NWN>())) void w
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
                 const int co = co0 + wm * WTG + i * 16 + (lane & 15);
-                if (lane < 16 && co < p.c_out) {
-                    if (p.plain && !p.accum) p.dbias[co] = v;
-                    else if (p.plain) p.dbias[co] += v;
-                    else atomicAdd(p.dbias + co, v);
-                }
+                if (lane < 16 && co < p.c_out) atomicAdd(p.dbias + co, v);
             }
     }
 }

@@ -588,7 +588,7 @@ def conv_wgrad_alloc(g: _Geo, w, need_db: bool):
         db = zeros_f32((g.Cout,), w.device) if need_db else None
         return zeros_f32((g.Cin, 2, 2, g.Cout // 4), w.device), db
     zero = not _wgrad_overwrites(g.fwd_desc(0))
-    db = _grad_buffer((g.Cout,), w.device, zero) if need_db else None
+    db = zeros_f32((g.Cout,), w.device) if need_db else None       # (the bias gradient is always ADDED to: include/transvae_hip.h)
     return _grad_buffer(tuple(w.shape), w.device, zero), db
 
 

@@ -109,9 +109,11 @@ int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const void* w, con
  *   dbias[co]          (+)= sum_p gy[p][co]                       (dbias may be NULL)
  *   gy : [batch, h_out, w_out, c_out] bf16 with `ldo` between pixels
  * The reduction over pixels is split over workgroups when the layer has few tiles; the partial tiles are then ADDED
- * into dw / dbias with fp32 atomics and the caller must pass zeroed buffers.  With a single pixel chunk every element
- * is WRITTEN exactly once and the buffers need no initialisation: tv_wgrad_tn_overwrites(d) says which of the two
+ * into dw with fp32 atomics and the caller must pass a zeroed dw.  With a single pixel chunk every element of dw
+ * is WRITTEN exactly once and dw needs no initialisation: tv_wgrad_tn_overwrites(d) says which of the two
  * tv_wgrad_tn will do for this geometry (1 = overwrites, 0 = accumulates, < 0 = bad descriptor).
+ * dbias is ALWAYS added to (the workgroups that share a range of output channels take the pixel steps in turn and each
+ * adds its share): pass it zeroed, or holding a running sum.
  * store_shuffle layers are handled by the caller as the transposed problem (x := the hi-res
  * gradient gathered with 2x2/stride-2 taps, gy := the layer input), so store_shuffle must be 0.
  * Requires c_in % 8 == 0, c_out % 8 == 0.

@@ -143,6 +143,10 @@ WGRAD3_CASES = [
     (5, 128, 128, 192, 192, 0),   # 81 920 pixels: split over many chunks, XCD-grouped order, ragged last chunk
     (2, 64, 64, 384, 384, 0),     # the Conv-FFN 3x3 of stage 2 (384 = 2 x 192 = 4 x 96)
     (1, 16, 32, 192, 192, 0),     # W < 64: not this kernel's -- falls through to the single-tap kernel
+    # the schedule variants (ring + 10 x variant, csrc/wgrad_kx3.hip): reads threaded into the MFMA phase, DMA pieces in either phase
+    (2, 32, 128, 192, 192, 14), (2, 32, 128, 192, 192, 24), (2, 32, 128, 192, 192, 34), (2, 32, 128, 192, 192, 44),
+    (3, 64, 64, 256, 128, 14), (3, 64, 64, 256, 128, 24), (3, 64, 64, 256, 128, 34), (3, 64, 64, 256, 128, 44),
+    (1, 8, 64, 96, 192, 14), (1, 8, 64, 96, 192, 24),     # 8 K-steps in all: prologue / tail of the ring
 ]
 
 

@@ -315,13 +315,21 @@ def test_two_rank_ddp_gradients_equal_the_single_process_step():
     loss1 = train_step(m, opt, x, 4, forward_loss, None, 4, counters)
     assert abs(float(loss1) - loss2) < 1e-5 * abs(float(loss1))
     assert abs(float(counters["grad_norm"]) - norm2) < 1e-4 * norm2
-    worst = 0.0
+    # Biases directly in front of a GroupNorm with ONE channel per group (the micro model's 32-channel ResBlocks: conv1.bias,
+    # the last convolution of a Down/Upsample ...) have an exact gradient of ZERO; what both runs hold there is the same bf16
+    # residue (norm ~1e-6, three to four orders below the other bias gradients) plus fp32 summation-order noise of the split
+    # sums, so a RELATIVE deviation says nothing: they are held to 1e-4 of the median bias-gradient norm instead.
+    import statistics
+    bias_scale = statistics.median(float(p.grad.norm()) for k, p in m.named_parameters() if k.endswith(".bias"))
+    errs = []
     for k, p in m.named_parameters():
         a, b = p.grad.detach().double().cpu(), torch.from_numpy(grads2[k]).double()
         n = float(a.norm())
         if n > 1e-12:
-            worst = max(worst, float((a - b).norm()) / n)
-    assert worst < 1e-4, worst
+            errs.append((float((a - b).norm()) / max(n, 1e-2 * bias_scale if k.endswith(".bias") else 0.0), k, n))
+    errs.sort(reverse=True)
+    print("median bias-gradient norm", bias_scale, " largest deviations (rel-L2, key, norm):", errs[:6])
+    assert errs[0][0] < 1e-4, errs[:6]
 
 
 # ---- transvae.optim.FusedAdamW against torch.optim.AdamW ------------------------------------------------

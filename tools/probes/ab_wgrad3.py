@@ -7,6 +7,7 @@ from transvae.hip import ops
 from transvae.hip import _lib as L
 dev = torch.device("cuda:0")
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+BIAS = os.environ.get("AB_BIAS", "1") == "1"      # with the bias gradient (the model's convolutions all have one)
 bf = torch.bfloat16
 lib = L.load()
 
@@ -21,7 +22,7 @@ def tm(fn, it=10):
 
 
 g = torch.Generator(device=dev).manual_seed(0)
-variants = [("single", (0, 0, 0)), ("kx3 r4", (1, 4, 0)), ("kx3 r3", (1, 3, 0))]
+variants = [("single", (0, 0, 0)), ("kx3 r4", (1, 4, 0)), ("kx3 r3", (1, 3, 0))] + [(f"kx3 r4 v{v}", (1, 4 + 10 * v, 0)) for v in (1, 2, 3, 4)]
 if len(sys.argv) > 2:
     variants += [(f"kx3 r4 b{b}", (1, 4, int(b))) for b in sys.argv[2].split(",")]
 for (hw, Cc) in [(256, 192), (128, 192), (64, 384)]:
@@ -35,17 +36,17 @@ for (hw, Cc) in [(256, 192), (128, 192), (64, 384)]:
     for rnd in range(3):
         for name, cfg in variants:
             lib.tv_set_wgrad_kx3(*cfg)
-            t = tm(lambda: ops.conv_wgrad(geo, w, x, gy, True))
+            t = tm(lambda: ops.conv_wgrad(geo, w, x, gy, BIAS))
             res.setdefault(name, []).append(t)
             if rnd == 0:
-                dw, db = ops.conv_wgrad(geo, w, x, gy, True)
+                dw, db = ops.conv_wgrad(geo, w, x, gy, BIAS)
                 if ref is None:
-                    ref = (dw.clone(), db.clone())
+                    ref = (dw.clone(), db.clone() if BIAS else None)
                 else:
-                    e = float((dw - ref[0]).norm() / ref[0].norm()), float((db - ref[1]).norm() / ref[1].norm())
+                    e = float((dw - ref[0]).norm() / ref[0].norm()), (float((db - ref[1]).norm() / ref[1].norm()) if BIAS else 0.0)
                     assert e[0] < 1e-4 and e[1] < 1e-4, (name, e)
     lib.tv_set_wgrad_kx3(1, 0, 0)
     for name, ts in res.items():
         t = min(ts)
-        print(f"wgrad c3s1 {Cc:4d}@{hw:<4d} mb{mb} {name:12s} min {t:7.3f} ms {f / t / 1e9:6.0f} TF/s   median {sorted(ts)[len(ts) // 2]:7.3f}", flush=True)
+        print(f"wgrad{' +bias' if BIAS else '      '} c3s1 {Cc:4d}@{hw:<4d} mb{mb} {name:12s} min {t:7.3f} ms {f / t / 1e9:6.0f} TF/s   median {sorted(ts)[len(ts) // 2]:7.3f}", flush=True)
     del x, gy, w
