@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--no-clamp", action="store_true", help="model without the P/ clamps (for the guard's A/B only)")
     ap.add_argument("--global-batch", type=int, default=256)
     ap.add_argument("--micro-batch", type=int, default=64)
+    ap.add_argument("--checkpointing", choices=["off", "resblocks", "all"], default="off",
+                    help="activation recompute (R/transvae/models/encoder.py:97-99,117-118): resblocks = the fused-op recompute of the "
+                         "CNN stages only (2 instead of 4 saved full-resolution tensors per ResBlock), all = every block like the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--kernel-only", action="store_true", help="only time the dominant kernel (for rocprofv3 --pmc passes)")
@@ -199,6 +202,8 @@ def main():
     with torch.device(dev):
         model = TransVAE(variant=args.variant, compression_ratio=16, latent_dim=32, clamp_latent=not args.no_clamp)
     init_scaled_(model, seed=0)
+    if args.checkpointing != "off":
+        model.enable_gradient_checkpointing(args.checkpointing)
     model.train()
     ddp = wrap_ddp(model, dev)
     if args.optimizer == "hip":
@@ -285,7 +290,8 @@ def main():
         gf = None if any(v is None for v in per_res) else sum(per_res) / len(per_res)
         res_name = "+".join(f"{r}x{r}" for r in resolutions)
         out = {
-            "metric": "images/sec train step, TransVAE-Large f16d32 256px bs256",
+            # BASELINE.json's metric string for its own configuration; any other variant / resolution / batch says so
+            "metric": f"images/sec train step, TransVAE-{args.variant.capitalize()} f16d32 {'+'.join(map(str, resolutions))}px bs{args.global_batch}",
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -295,6 +301,7 @@ def main():
                        "parallelism": f"dp{world}",
                        "weights": "random fan-in scaled", "loss": "L1 + 1e-8 KL (vae_loss.py:83-84,94-96)",
                        "numerics": "P/ clamps on mu/logvar, skip-on-non-finite guard",
+                       "checkpointing": args.checkpointing,
                        "lr": args.lr, "lr_warmup_steps": args.lr_warmup_steps,
                        "optimizer": "transvae.optim.FusedAdamW (HIP multi-tensor)" if args.optimizer == "hip" else "torch.optim.AdamW(fused)"},
             "final_loss": round(final_loss, 5),

@@ -190,7 +190,7 @@ def _wg(ctx, iw, ib, geo, w, x, gz):
             return None, None
         ops.acc_stats["autograd"] += 1
     if _SIDE["on"] and geo.mode not in ("shuf", "c3up"):
-        out = ops.conv_wgrad_alloc(geo, w, need_b)
+        out = ops.conv_wgrad_alloc(geo, w, need_b, x, gz)
         main = torch.cuda.current_stream()
         side = _side_stream(x.device)
         side.wait_stream(main)                      # gz (and the zero fills) are ready

@@ -221,19 +221,80 @@ def _desc(**kw) -> L.ConvDesc:
     return d
 
 
+# ---- launches over more than 2 GiB of activations --------------------------------------------------------------------------
+# The fast staging paths of the kernels address an operand through a buffer descriptor with 32-bit byte offsets, i.e. one
+# launch sees < 2 GiB of each activation tensor (a micro-batch of 64 Large images at 256 x 256 is 1.6 GB per 192-channel
+# tensor; 128 images are 3.2 GB).  Images are independent through every layer, so a larger tensor is simply launched in
+# batch chunks -- forward and data gradient chunk by chunk, the weight gradient with the later chunks ADDING
+# (tv_wgrad_tn_acc) -- instead of dropping to the generic 64-bit addressing path of the kernels (2-3x slower).
+_LAUNCH_BYTES = (1 << 31) - (1 << 26)
+
+
+def _batch_chunks(batch: int, tensors, align: int = 1):
+    """None when one launch covers it, else [(first row, rows)] with every listed tensor's slice below the launch limit.
+    `tensors` hold `batch` leading rows each (images, or tokens for 'linear'); chunks are multiples of `align` rows."""
+    per_row = 0
+    for t in tensors:
+        if t is not None:
+            per_row = max(per_row, (t.numel() // batch) * t.element_size())
+    if per_row * batch < _LAUNCH_BYTES:
+        return None
+    rows = max(align, (_LAUNCH_BYTES // per_row) // align * align)
+    n = -(-batch // rows)
+    rows = -(-(-(-batch // n)) // align) * align          # even chunks
+    return [(s, min(rows, batch - s)) for s in range(0, batch, rows)]
+
+
+def _row_ptr(t, batch: int, row: int):
+    """device pointer of row `row` of a tensor with `batch` leading rows (None stays None)"""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + row * (t.numel() // batch) * t.element_size())
+
+
+def _desc_rows(desc: L.ConvDesc, rows: int) -> L.ConvDesc:
+    d = L.ConvDesc()
+    C.memmove(C.byref(d), C.byref(desc), C.sizeof(L.ConvDesc))
+    d.batch = rows
+    return d
+
+
 def igemm(desc: L.ConvDesc, x, w, bias, residual, pre, out):
     lib = L.load()
-    L.check(lib.tv_igemm_nt(C.byref(desc), _p(x), _p(w), _p(bias), _p(residual), _p(pre), _p(out), _stream()), "tv_igemm_nt")
+    ch = _batch_chunks(desc.batch, (x, residual, pre, out))
+    if ch is None:
+        L.check(lib.tv_igemm_nt(C.byref(desc), _p(x), _p(w), _p(bias), _p(residual), _p(pre), _p(out), _stream()), "tv_igemm_nt")
+        return
+    B = desc.batch
+    for s, c in ch:
+        L.check(lib.tv_igemm_nt(C.byref(_desc_rows(desc, c)), _row_ptr(x, B, s), _p(w), _p(bias), _row_ptr(residual, B, s),
+                                _row_ptr(pre, B, s), _row_ptr(out, B, s), _stream()), "tv_igemm_nt")
 
 
-def wgrad(desc: L.ConvDesc, x, gy, dw, dbias):
+def wgrad(desc: L.ConvDesc, x, gy, dw, dbias, _acc: bool = False):
+    """dw (and dbias) of one layer.  Chunked launches: the first chunk follows the kernel's own overwrite / accumulate
+    plan for ITS geometry (callers size-check with wgrad_plan_desc), later chunks add."""
     lib = L.load()
-    L.check(lib.tv_wgrad_tn(C.byref(desc), _p(x), _p(gy), _p(dw), _p(dbias), _stream()), "tv_wgrad_tn")
+    ch = _batch_chunks(desc.batch, (x, gy))
+    fn_first = lib.tv_wgrad_tn_acc if _acc else lib.tv_wgrad_tn
+    if ch is None:
+        L.check(fn_first(C.byref(desc), _p(x), _p(gy), _p(dw), _p(dbias), _stream()), "tv_wgrad_tn")
+        return
+    B = desc.batch
+    for i, (s, c) in enumerate(ch):
+        fn = fn_first if i == 0 else lib.tv_wgrad_tn_acc
+        L.check(fn(C.byref(_desc_rows(desc, c)), _row_ptr(x, B, s), _row_ptr(gy, B, s), _p(dw), _p(dbias), _stream()), "tv_wgrad_tn")
 
 
 def wgrad_acc(desc: L.ConvDesc, x, gy, dw, dbias):
     """dw += ..., dbias += ...  (the buffers hold the gradients of earlier micro-batches)"""
-    L.check(L.load().tv_wgrad_tn_acc(C.byref(desc), _p(x), _p(gy), _p(dw), _p(dbias), _stream()), "tv_wgrad_tn_acc")
+    wgrad(desc, x, gy, dw, dbias, _acc=True)
+
+
+def wgrad_plan_desc(desc: L.ConvDesc, x, gy) -> L.ConvDesc:
+    """The descriptor of the FIRST launch of wgrad(desc, x, gy, ...): what tv_wgrad_tn_overwrites must be asked about."""
+    ch = _batch_chunks(desc.batch, (x, gy))
+    return desc if ch is None else _desc_rows(desc, ch[0][1])
 
 
 # In-place gradient accumulation across the micro-batches of one optimizer step (transvae.parallel.train_step switches it on
@@ -397,8 +458,11 @@ def conv_forward(x, w, bias, residual, mode: str, act_id: int, want_pre, rope=No
         _require(mode == "linear" and residual is None and pre is None and act_id == L.ACT_NONE, "rope epilogue: plain projection only")
         _require(tab.dtype == torch.float32 and tab.is_contiguous() and tuple(tab.shape) == (tokens, 4, 32) and g.B % tokens == 0,
                  "rope table must be contiguous fp32 [tokens, 4, 32] and the rows whole images")
-        L.check(L.load().tv_igemm_nt_rope(C.byref(g.fwd_desc(act_id)), _p(x), _p(wb), _p(bias), _p(out), _p(tab), int(tokens), int(cols),
-                                          _stream()), "tv_igemm_nt_rope")
+        d = g.fwd_desc(act_id)
+        ch = _batch_chunks(d.batch, (x, out), align=int(tokens)) or [(0, d.batch)]
+        for s0, c0 in ch:
+            L.check(L.load().tv_igemm_nt_rope(C.byref(_desc_rows(d, c0)), _row_ptr(x, d.batch, s0), _p(wb), _p(bias), _row_ptr(out, d.batch, s0),
+                                              _p(tab), int(tokens), int(cols), _stream()), "tv_igemm_nt_rope")
         return out, pre, g, w
     igemm(g.fwd_desc(act_id), x, wb, bias, residual, pre, out)
     return out, pre, g, w
@@ -410,8 +474,10 @@ def _igemm_bwd(desc, gz, wt, residual, aux, aux_act, dx):
         igemm(desc, gz, wt, None, residual, None, dx)
     else:
         lib = L.load()
-        L.check(lib.tv_igemm_nt_actgrad(C.byref(desc), _p(gz), _p(wt), _p(residual), _p(aux), aux_act, _p(dx), _stream()),
-                "tv_igemm_nt_actgrad")
+        B = desc.batch
+        for s, c in (_batch_chunks(B, (gz, residual, aux, dx)) or [(0, B)]):
+            L.check(lib.tv_igemm_nt_actgrad(C.byref(_desc_rows(desc, c)), _row_ptr(gz, B, s), _p(wt), _row_ptr(residual, B, s),
+                                            _row_ptr(aux, B, s), aux_act, _row_ptr(dx, B, s), _stream()), "tv_igemm_nt_actgrad")
 
 
 # nearest-x2 upsample followed by a 3x3 / pad-1 convolution, in polyphase form.  Output row Y = 2y' - py of the [2H]
@@ -582,12 +648,14 @@ def _grad_buffer(shape, device, zero: bool):
     return zeros_f32(shape, device) if zero else torch.empty(shape, dtype=torch.float32, device=device)
 
 
-def conv_wgrad_alloc(g: _Geo, w, need_db: bool):
-    """Outputs of conv_wgrad (allocated on the stream that will consume them), zeroed only where the kernel accumulates."""
+def conv_wgrad_alloc(g: _Geo, w, need_db: bool, x=None, gz=None):
+    """Outputs of conv_wgrad (allocated on the stream that will consume them), zeroed only where the kernel accumulates.
+    x / gz: the operands, when the launch may be chunked (> 2 GiB): the plan is that of the first chunk."""
     if g.mode == "shuf":
         db = zeros_f32((g.Cout,), w.device) if need_db else None
         return zeros_f32((g.Cin, 2, 2, g.Cout // 4), w.device), db
-    zero = not _wgrad_overwrites(g.fwd_desc(0))
+    d0 = g.fwd_desc(0)
+    zero = not _wgrad_overwrites(wgrad_plan_desc(d0, x, gz) if x is not None else d0)
     db = zeros_f32((g.Cout,), w.device) if need_db else None       # (the bias gradient is always ADDED to: include/transvae_hip.h)
     return _grad_buffer(tuple(w.shape), w.device, zero), db
 
@@ -600,7 +668,7 @@ def conv_wgrad(g: _Geo, w, x, gz, need_db: bool, out=None):
         # gradient under 4x4 / stride-2 taps; the other operand: the layer input), folded back onto the 3x3 taps
         d = _desc(batch=g.B, h_in=g.Ho, w_in=g.Wo, c_in=g.Cout, ldx=g.Cout, h_out=g.H, w_out=g.W, c_out=g.Cin, ldo=g.Cin,
                   kh=4, kw=4, stride=2, pad=1)
-        d16 = _grad_buffer((g.Cin, 4, 4, g.Cout), dev, not _wgrad_overwrites(d))
+        d16 = _grad_buffer((g.Cin, 4, 4, g.Cout), dev, not _wgrad_overwrites(wgrad_plan_desc(d, gz, x)))
         wgrad(d, gz, x, d16, None)
         dw = _up_fold_wgrad(d16, g.Cout, g.Cin)
         db = gz.view(-1, g.Cout).sum(0, dtype=torch.float32) if need_db else None
@@ -610,7 +678,7 @@ def conv_wgrad(g: _Geo, w, x, gz, need_db: bool, out=None):
         wgrad(g.fwd_desc(0), x, gz, dw, db)
         return dw, db
     if g.mode != "shuf":
-        dw, db = conv_wgrad_alloc(g, w, need_db)
+        dw, db = conv_wgrad_alloc(g, w, need_db, x, gz)
         wgrad(g.fwd_desc(0), x, gz, dw, db)
         return dw, db
     db = zeros_f32((g.Cout,), dev) if need_db else None

@@ -50,8 +50,12 @@ class TransVAEDecoder(nn.Module):
         self.conv_out = nn.Conv2d(base_dims[-1], output_channels, 3, padding=1)
         self.gradient_checkpointing = False
 
-    def enable_gradient_checkpointing(self):
-        self.gradient_checkpointing = True
+    def enable_gradient_checkpointing(self, scope: str = "all"):
+        """scope "all": every block, like the reference's toggle; "resblocks": only the CNN stages' fused-op recompute (the
+        stages that hold the large tensors; no convolution runs twice)."""
+        if scope not in ("all", "resblocks"):
+            raise ValueError(f"unknown checkpointing scope {scope!r}")
+        self.gradient_checkpointing = scope
 
     @ops.hip_entry
     def forward_nhwc(self, z: torch.Tensor, taps=None) -> torch.Tensor:
@@ -64,7 +68,7 @@ class TransVAEDecoder(nn.Module):
         for i, stage in enumerate(self.stages):
             for j, block in enumerate(stage):
                 if self.gradient_checkpointing and self.training:
-                    h = _checkpointed(block, h)
+                    h = _checkpointed(block, h, self.gradient_checkpointing)
                 else:
                     h = block.forward_nhwc(h)
                 h = _tap(taps, f"decoder.stages.{i}.{j}", h)

@@ -27,13 +27,15 @@ def _tap(taps, key, h):
     return h
 
 
-def _checkpointed(block, h):
+def _checkpointed(block, h, scope="all"):
     """The activation-checkpointing toggle (R/transvae/models/encoder.py:97-99,117-118; decoder.py:98-100,118-119).
     ResBlocks (the stages that hold the large tensors) recompute only their two GroupNorm+SiLU outputs in the backward pass
     (fused-op recompute: no convolution runs twice, 2 saved full-resolution tensors per block instead of 4); TransVAE
     blocks are re-run as a whole like the reference does."""
     if getattr(block, "supports_fused_recompute", False) and isinstance(block.shortcut, nn.Identity):
         return block.forward_nhwc(h, recompute=True)
+    if scope == "resblocks":
+        return block.forward_nhwc(h)
     return torch.utils.checkpoint.checkpoint(block.forward_nhwc, h, use_reentrant=False)
 
 
@@ -62,8 +64,12 @@ class TransVAEEncoder(nn.Module):
                 self.downsamples.append(Downsample(dim, base_dims[i + 1], use_dc_path=use_dc_path))
         self.gradient_checkpointing = False
 
-    def enable_gradient_checkpointing(self):
-        self.gradient_checkpointing = True
+    def enable_gradient_checkpointing(self, scope: str = "all"):
+        """scope "all": every block, like the reference's toggle; "resblocks": only the CNN stages' fused-op recompute (the
+        stages that hold the large tensors; no convolution runs twice)."""
+        if scope not in ("all", "resblocks"):
+            raise ValueError(f"unknown checkpointing scope {scope!r}")
+        self.gradient_checkpointing = scope
 
     def _stem(self, x: torch.Tensor) -> torch.Tensor:
         B, C, H, W = x.shape
@@ -85,7 +91,7 @@ class TransVAEEncoder(nn.Module):
         for i, stage in enumerate(self.stages):
             for j, block in enumerate(stage):
                 if self.gradient_checkpointing and self.training:
-                    h = _checkpointed(block, h)
+                    h = _checkpointed(block, h, self.gradient_checkpointing)
                 else:
                     h = block.forward_nhwc(h)
                 h = _tap(taps, f"encoder.stages.{i}.{j}", h)

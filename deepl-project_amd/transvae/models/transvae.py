@@ -142,9 +142,11 @@ class TransVAE(nn.Module):
         f, d = int(cfg[1:].split("d")[0]), int(cfg.split("d")[1])
         return cls(variant=variant, compression_ratio=f, latent_dim=d, **kwargs)
 
-    def enable_gradient_checkpointing(self):
-        self.encoder.enable_gradient_checkpointing()
-        self.decoder.enable_gradient_checkpointing()
+    def enable_gradient_checkpointing(self, scope: str = "all"):
+        """R/transvae/models/transvae.py:269-272.  scope (extension, default = the reference's behaviour): "resblocks" keeps
+        the recompute to the CNN stages' GroupNorm+SiLU outputs (encoder.py: _checkpointed)."""
+        self.encoder.enable_gradient_checkpointing(scope)
+        self.decoder.enable_gradient_checkpointing(scope)
 
     def get_num_params(self) -> dict:
         enc = sum(p.numel() for p in self.encoder.parameters())

@@ -131,6 +131,46 @@ def test_conv_forward_backward(case, dma):
         _lib.load().tv_set_dma(1)
 
 
+CHUNK_CASES = [
+    ("linear", (6 * 64, 64), (128,), "gelu", True),          # 6 "images" of 64 tokens
+    ("c3s1", (5, 16, 64, 192), (192, 3, 3), None, True),      # the kx-triple weight gradient, chunk by chunk
+    ("c3s2", (4, 12, 8, 64), (128, 3, 3), "silu", False),
+    ("c3up", (3, 8, 8, 64), (96, 3, 3), "silu", True),
+    ("unshuf", (4, 8, 12, 64), (128, 2, 2), None, True),
+    ("shuf", (3, 6, 5, 128), (256, 1, 1), None, False),
+]
+
+
+@pytest.mark.parametrize("case", CHUNK_CASES, ids=[c[0] for c in CHUNK_CASES])
+def test_launches_in_batch_chunks_equal_one_launch(case, monkeypatch):
+    """ops._batch_chunks: an activation tensor of 2 GiB or more (micro-batch 128 at 256 x 256: 3.2 GB per 192-channel tensor)
+    is launched in batch chunks -- forward and data gradient chunk by chunk, the weight gradient with the later chunks adding.
+    With the launch limit lowered so that these small layers split into 2-3 chunks, outputs and activation gradients must be
+    bit-identical to the single launch (images are independent) and the weight / bias gradients equal to fp32 summation order."""
+    from transvae.hip import ops
+    mode, xs, ws, act, use_res = case
+    x, w, b = _mk(mode, xs, ws, seed=91)
+
+    def run():
+        xd = x.to(dev(), BF).requires_grad_(True)
+        wd = w.to(dev()).requires_grad_(True)
+        bd = b.to(dev()).requires_grad_(True)
+        y0 = ops.conv(xd, wd, bd, None, mode=mode, act=act)
+        rd = r16(gen(*y0.shape, seed=7)).to(dev(), BF).requires_grad_(True) if use_res else None
+        y = ops.conv(xd, wd, bd, rd, mode=mode, act=act)
+        y.backward(r16(gen(*y.shape, seed=8)).to(dev(), BF))
+        torch.cuda.synchronize()
+        return y.detach(), xd.grad, wd.grad, bd.grad
+    one = run()
+    rows = xs[0]
+    per_row = max(x.numel() // rows, one[0].numel() // rows) * 2
+    monkeypatch.setattr(ops, "_LAUNCH_BYTES", per_row * (rows // 2) + 1)     # at most half of the rows per launch
+    assert ops._batch_chunks(rows, (x.to(BF), one[0])) is not None
+    many = run()
+    assert torch.equal(one[0], many[0]) and torch.equal(one[1], many[1])
+    assert rel(many[2], one[2]) < 1e-5 and rel(many[3], one[3]) < 1e-5
+
+
 WGRAD3_CASES = [
     # (B, H, W, Cin, Cout, ring): 3x3 / stride-1 weight gradient through the kx-triple kernel (csrc/wgrad_kx3.hip: image rows of
     # >= 64 pixels; one K-step = 64 pixels of one image row + its two neighbours) -- both tile shapes, one / several K-steps

@@ -190,3 +190,19 @@ def test_reference_written_checkpoint_loads_and_round_trips(golden_dir, tmp_path
     for k, e in exp["params"].items():
         got = sd[k].detach().flatten()[e["idx"]]
         assert torch.allclose(got, torch.tensor(e["val"]), rtol=1e-4, atol=1e-6), k
+
+
+def test_batch_chunk_plan_for_tensors_beyond_the_launch_limit():
+    """ops._batch_chunks (host logic): tensors below 2 GiB go out in one launch; larger ones in even chunks of whole rows /
+    whole images (`align`), every chunk's slice below the limit."""
+    import torch
+    from transvae.hip import ops
+    small = torch.empty((64, 4), dtype=torch.bfloat16)
+    assert ops._batch_chunks(64, (small, None)) is None
+    meta = torch.empty((128, 256, 256, 192), dtype=torch.bfloat16, device="meta")     # micro-batch 128 at 256 x 256: 3.2 GB
+    ch = ops._batch_chunks(128, (meta,))
+    assert ch == [(0, 64), (64, 64)]
+    tok = torch.empty((96 * 4096, 1536 * 2), dtype=torch.bfloat16, device="meta")     # 96 images x 4096 tokens, 2.4 GB
+    ch = ops._batch_chunks(96 * 4096, (tok,), align=4096)
+    assert sum(c for _, c in ch) == 96 * 4096 and all(s % 4096 == 0 and c % 4096 == 0 for s, c in ch)
+    assert all(c * 1536 * 2 * 2 < (1 << 31) for _, c in ch) and len(ch) == 2
