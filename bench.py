@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--checkpointing", choices=["off", "resblocks", "all"], default="off",
                     help="activation recompute (R/transvae/models/encoder.py:97-99,117-118): resblocks = the fused-op recompute of the "
                          "CNN stages only (2 instead of 4 saved full-resolution tensors per ResBlock), all = every block like the reference")
+    ap.add_argument("--grad-exchange", choices=["fp32", "bf16"], default="fp32",
+                    help="N > 1: gradient all-reduce in fp32 (4.2 GB per step, the reference's DDP) or with bf16 buckets (2.1 GB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--kernel-only", action="store_true", help="only time the dominant kernel (for rocprofv3 --pmc passes)")
@@ -205,7 +207,7 @@ def main():
     if args.checkpointing != "off":
         model.enable_gradient_checkpointing(args.checkpointing)
     model.train()
-    ddp = wrap_ddp(model, dev)
+    ddp = wrap_ddp(model, dev, grad_exchange=args.grad_exchange)
     if args.optimizer == "hip":
         from transvae.optim import FusedAdamW
         opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0)
@@ -298,7 +300,7 @@ def main():
             "config": {"workload": f"TransVAE-{args.variant} f16d32 {res_name} train step "
                                    f"(fwd+bwd+grad all-reduce+clip+AdamW), global batch {args.global_batch}",
                        "global_batch": args.global_batch, "micro_batch": [micro[r] for r in resolutions] if len(resolutions) > 1 else args.micro_batch,
-                       "parallelism": f"dp{world}",
+                       "parallelism": f"dp{world}", "gradient_exchange": args.grad_exchange if world > 1 else None,
                        "weights": "random fan-in scaled", "loss": "L1 + 1e-8 KL (vae_loss.py:83-84,94-96)",
                        "numerics": "P/ clamps on mu/logvar, skip-on-non-finite guard",
                        "checkpointing": args.checkpointing,

@@ -57,13 +57,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, x_np, q):
+def _worker(rank, world, port, x_np, q, grad_exchange="fp32"):
     x = torch.from_numpy(x_np)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
     net = Net()
-    ddp = wrap_ddp(net, None)
+    ddp = wrap_ddp(net, None, grad_exchange=grad_exchange)
     assert isinstance(ddp, nn.parallel.DistributedDataParallel)
     opt = torch.optim.AdamW(net.parameters(), lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0)
     calls = {"sync": 0, "nosync": 0}
@@ -104,6 +104,37 @@ def test_two_rank_gloo_step_equals_single_process():
     assert nosync_calls == 2 * 2          # 3 micro-batches per step: 2 without sync, the last one syncs
     for k, v in ref.state_dict().items():
         assert torch.allclose(torch.from_numpy(sd[k]), v, rtol=1e-4, atol=1e-6), k
+
+
+def test_two_rank_gloo_bf16_gradient_exchange_stays_within_bf16_of_the_fp32_exchange():
+    """wrap_ddp(grad_exchange="bf16"): the buckets cross the wire as bf16 (half the bytes of the 4.2 GB fp32 exchange, SURVEY
+    section 5).  One step on two ranks with each exchange: the parameters after the step agree to what one bf16 rounding
+    of the summed gradients can move an AdamW update (lr 1e-2: the update is +-lr at most, its relative change ~2^-8)."""
+    torch.manual_seed(1)
+    x = torch.rand(12, 3, 8, 8)
+    ctx = mp.get_context("spawn")
+    out = {}
+    for mode in ("fp32", "bf16"):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, x.numpy(), q, mode)) for r in range(2)]
+        for p in procs:
+            p.start()
+        out[mode], _ = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    differ = 0
+    for k in out["fp32"]:
+        a, b = torch.from_numpy(out["fp32"][k]), torch.from_numpy(out["bf16"][k])
+        assert torch.allclose(a, b, rtol=0, atol=2 * 2e-2 * 2.0 ** -7), k      # two steps of lr 1e-2, direction changed by <= 2^-7
+        differ += int(not torch.equal(a, b))
+    assert differ > 0          # the hook did run (the exchange WAS rounded)
+
+
+def test_wrap_ddp_rejects_unknown_exchange():
+    with pytest.raises(ValueError):
+        wrap_ddp(Net(), None, grad_exchange="fp8")
 
 
 # ---- numerical guards of the train step (R/train_2.py:266-273, 316-318, 328-338; R/train.py:610-612) ------------
