@@ -54,6 +54,7 @@ def main():
                       "90pct_of_the_bytes_ready_at_frac_of_backward": p90["ready_frac_of_backward"],
                       "last_bucket_mib": b[-1]["mib"], "last_bucket_ready_frac": b[-1]["ready_frac_of_backward"],
                       "what": "device time at which each bucket's gradients were complete; no all-reduce ran (world size 1)"}
+    sys.stdout.flush()
     print(json.dumps(rep, indent=1))
     dist.destroy_process_group()
 
