@@ -20,10 +20,17 @@
 // 4-pixel half of the fragment are compile-time offsets (the step loop is unrolled RING times), so the load phase has no
 // address arithmetic.
 //
-// x image of a K-step: tile row 0 = left neighbour of the segment (zeros at the image's left edge: out-of-range DMA
-// offset = the convolution's zero padding), rows 1..64 = the 64 pixels, row 65 = right neighbour; padding in y = the
-// whole step's x rows out of range.  Tiles are pixel-major ([row][channels], 16-byte chunks XOR-swizzled on the DMA source
-// address and on the read address), fragments come out through ds_read_b64_tr_b16.
+// x image of a K-step (64 output pixels = 64 / SEG pieces of image rows, SEG = min(image width, 64) in {16, 32, 64}): each
+// segment takes SS = SEG + 2 rounded up to a multiple of 8 tile rows -- row 0 = left neighbour of the segment (zeros at the
+// image's left edge: out-of-range DMA offset = the convolution's zero padding), rows 1..SEG = its pixels, row SEG + 1 =
+// right neighbour; padding in y = the segment's x rows out of range.  Tiles are pixel-major ([row][channels], 16-byte
+// chunks XOR-swizzled on the DMA source address and on the read address), fragments come out through ds_read_b64_tr_b16.
+//
+// Which pixel sits in which k slot of the MFMA is free as long as both operands agree: lane group g (= lane >> 4), half h,
+// element q of a 32-pixel half-step hold pixel 16 h + 4 g + q.  A 32-lane half of a transposing read then covers 8
+// CONSECUTIVE tile rows (at any first row: the x image is read at row offsets 0 / 1 / 2), the swizzle is keyed on row & 7,
+// and because every segment stride is a multiple of 8 rows the offsets of h (16 pixels) and of the second half-step
+// (32 pixels) are the same constant for every lane, whatever the segment length.
 #include "common.h"
 
 #include <type_traits>
@@ -41,20 +48,17 @@ struct Kx3Args {
     unsigned x_bytes;
 };
 
-// physical 16-byte slot of logical chunk c in row r of a [rows][TW channels] tile: conflict-free transposing reads for ANY
-// first row of the 4-row blocks (the x image is read at row offsets 0 / 1 / 2)
+// physical 16-byte slot of logical chunk c in row r of a [rows][TW channels] tile: 8 consecutive rows (any first row) put
+// their 32-byte pieces of one channel group on 8 different bank groups -> conflict-free transposing reads
 template <int TW>
 __device__ __forceinline__ int kx_swz(int c, int r) {
-    if constexpr (TW % 128 == 0) {
-        const int s = (((r >> 3) & 1) << 3) | ((r & 3) << 1);
-        return (c & ~15) | ((c & 15) ^ s);
-    } else if constexpr (TW % 64 == 0) {
-        const int s = (((r >> 3) & 1) << 2) | (((r >> 1) & 1) << 1);
-        return (c & ~7) | ((c & 7) ^ s);
-    } else {   // 96: rows of 6 x 32 bytes; consecutive rows are 6 bank groups apart, rows 8 apart collide -> XOR bit 1
+    if constexpr (TW % 128 == 0) {          // rows are whole bank rows: XOR the 32-byte granule index with r & 7
+        return (c & ~15) | ((c & 15) ^ ((r & 7) << 1));
+    } else if constexpr (TW % 64 == 0) {    // 64 / 192: consecutive rows are 4 granules apart: XOR the low two bits with (r >> 1) & 3
+        return (c & ~7) | ((c & 7) ^ (((r >> 1) & 3) << 1));
+    } else {                                // 96: rows are 6 granules apart (0, 6, 4, 2, 0, ...): rows 4 apart collide -> XOR bit 0
         static_assert(TW % 32 == 0, "tile width");
-        const int s = ((r >> 3) & 1) << 1;
-        return (c & ~3) | ((c & 3) ^ s);
+        return (c & ~3) | ((c & 3) ^ (((r >> 2) & 1) << 1));
     }
 }
 
@@ -70,11 +74,9 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr int kx_xrows(int cx) {   // >= 66 rows and a whole number of 1 KiB DMA pieces
-    int r = 66;
-    while ((r * cx) % 64 != 0) ++r;
-    return r;
-}
+constexpr int kx_seg_stride(int seg) { return (seg + 2 + 7) / 8 * 8; }                 // tile rows per segment: 24 / 40 / 72
+constexpr int kx_x_pieces(int seg, int cx) { return ((64 / seg) * kx_seg_stride(seg) * cx + 63) / 64; }   // 1 KiB pieces of the x tile
+constexpr int kx_stage_bytes(int tg, int tx, int seg) { return 64 * tg * 2 + kx_x_pieces(seg, tx / 8) * 1024; }
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -95,18 +97,20 @@ __device__ __forceinline__ void static_for(F&& f) {
 // (group 1).  Reads threaded into the MFMA phase make a group read K-step t while the other group is already in load phase
 // t + 1, so a piece issued in a LOAD phase may then only overwrite the slot of step t - 2 (lookahead RING - 2); pieces issued
 // in an MFMA phase may always overwrite the slot of step t - 1.
-template <int TG, int TX, int NWM, int NWN, int RING, int VAR>
+template <int TG, int TX, int NWM, int NWN, int RING, int VAR, int SEG>
 __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     constexpr int NW = 8, BKP = 64;
     static_assert(NWM * NWN == NW, "8 waves");
+    static_assert(SEG == 16 || SEG == 32 || SEG == 64, "segment = min(image width, 64)");
     constexpr int CG = TG / 8, CX = TX / 8;
-    constexpr int XROWS = kx_xrows(CX);
+    constexpr int NSEG = BKP / SEG, SS = kx_seg_stride(SEG);   // segments per K-step, tile rows per segment
     constexpr int G_PIECES = BKP * CG / 64;                    // 1 KiB pieces of the gy tile
-    constexpr int X_PIECES = (66 * CX + 63) / 64;              // ... of the 66 used rows of the x tile
+    constexpr int X_PIECES = kx_x_pieces(SEG, CX);             // ... of the x tile
     static_assert(G_PIECES % NW == 0, "gy pieces divide over the waves");
     constexpr int G_IT = G_PIECES / NW, X_IT = (X_PIECES + NW - 1) / NW, P_IT = G_IT + X_IT;
     constexpr int XR = X_PIECES % NW;                          // waves below XR issue X_IT x pieces, the others X_IT - 1 (XR != 0)
-    constexpr int G_BYTES = BKP * TG * 2, X_BYTES = XROWS * TX * 2;
+    constexpr int G_BYTES = BKP * TG * 2, X_BYTES = X_PIECES * 1024;
+    constexpr int KK_ROWS = SEG == 64 ? 32 : (32 / SEG) * SS, H_ROWS = SEG == 16 ? SS : 16;   // x-tile rows of 32 / 16 pixels
     constexpr int X_REGION = RING * G_BYTES;
     static_assert(RING * (G_BYTES + X_BYTES) <= 160 * 1024, "LDS");
     constexpr int WTG = TG / NWM, WTX = TX / NWN, MF = WTG / 16, NF = WTX / 16;
@@ -152,13 +156,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
         const int r = id / CG, sl = id - r * CG;
         g_voff[it] = (r * p.ldo + co0 + kx_swz<TG>(sl, r) * 8) * 2;
     }
-    int x_voff[X_IT], x_need[X_IT];     // need: bit 0 = pixel of the segment, bit 1 = left neighbour, bit 2 = right neighbour; 0 = unused row
+    // need: three bits per segment -- bit 0 = pixel of the segment, bit 1 = its left neighbour, bit 2 = its right neighbour; 0 = unused row
+    int x_voff[X_IT], x_need[X_IT];
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
         const int id = (it * NW + wave) * 64 + lane;
         const int R = id / CX, sl = id - R * CX;
-        x_need[it] = R == 0 ? 2 : (R == 65 ? 4 : (R > 65 ? 0 : 1));
-        x_voff[it] = (R * p.ldx + ci0 + kx_swz<TX>(sl, R) * 8) * 2;            // relative to pixel (pz + dty w - 1)
+        const int sg = R / SS, o = R - sg * SS;                                  // segment, row inside it (0 = left neighbour)
+        const int need = o == 0 ? 2 : (o == SEG + 1 ? 4 : (o > SEG + 1 ? 0 : 1));
+        x_need[it] = sg < NSEG ? need << (3 * sg) : 0;
+        x_voff[it] = ((sg * SEG + o) * p.ldx + ci0 + kx_swz<TX>(sl, R) * 8) * 2;   // relative to pixel (pz + dty w - 1)
     }
     const long long dshift = ((long long)dty * w - 1) * p.ldx;                 // elements
     const bf16* xb = p.x + dshift;
@@ -167,10 +174,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
 
     // piece iteration IT of K-step `step` into ring slot `slot`: IT < G_IT a gy piece, else an x piece
     auto x_have = [&](int step) {   // one scalar mask per step against one per-lane bit: no divergent control flow around the DMA issue
-        const int pz = p_begin + step * BKP;
-        const int x0 = pz & (w - 1);
-        const int uy = ((pz & (hw - 1)) >> p.w_shift) + dty;
-        return ((unsigned)uy < (unsigned)p.h) ? (1 | (x0 != 0 ? 2 : 0) | (x0 + BKP < w ? 4 : 0)) : 0;
+        int have = 0;
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            const int pz = p_begin + step * BKP + sg * SEG;
+            const int x0 = pz & (w - 1);
+            const int uy = ((pz & (hw - 1)) >> p.w_shift) + dty;
+            if ((unsigned)uy < (unsigned)p.h) have |= (1 | (x0 != 0 ? 2 : 0) | (x0 + SEG < w ? 4 : 0)) << (3 * sg);
+        }
+        return have;
     };
     auto issue_piece = [&](auto it_c, int step, int slot, int have) {
         constexpr int IT = decltype(it_c)::value;
@@ -189,37 +201,39 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
         static_for<P_IT>([&](auto it_c) { issue_piece(it_c, step, slot, have); });
     };
 
-    // ---- fragment addressing: lane (g = lane>>4, q = (lane>>2)&3, pp = lane&3) supplies row 8g + 4h + q (+ 32 kk), columns
-    // base + 4pp .. +3 of a 32-pixel slice.  Everything but the lane's own part is an immediate.
+    // ---- fragment addressing: lane (g = lane>>4, q = (lane>>2)&3, pp = lane&3) supplies the row of pixel 4g + q (+ 16 h + 32 kk),
+    // columns base + 4pp .. +3.  Everything but the lane's own part is an immediate.
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     unsigned a_base[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
-        const int r = 8 * g + q;
+        const int r = 4 * g + q;
         const int col = wm * WTG + i * 16 + 4 * pp;
         a_base[i] = smem_addr + r * (TG * 2) + kx_swz<TG>(col >> 3, r) * 16 + (pp & 1) * 8;
     }
-    unsigned b_base[2][3][NF];
+    unsigned b_base[3][NF];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int tp = 0; tp < 3; ++tp) {
+        const int R = 4 * g + q + tp;                 // tile row of tap kx = tp for pixel 4g + q (row 0 of a segment = left neighbour)
 #pragma unroll
-        for (int tp = 0; tp < 3; ++tp) {
-            const int R = 8 * g + 4 * h + q + tp;                 // tile row of tap kx = tp for pixel 8g + 4h + q
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                const int col = wn * WTX + j * 16 + 4 * pp;
-                b_base[h][tp][j] = smem_addr + X_REGION + R * (TX * 2) + kx_swz<TX>(col >> 3, R) * 16 + (pp & 1) * 8;
-            }
+        for (int j = 0; j < NF; ++j) {
+            const int col = wn * WTX + j * 16 + 4 * pp;
+            b_base[tp][j] = smem_addr + X_REGION + R * (TX * 2) + kx_swz<TX>(col >> 3, R) * 16 + (pp & 1) * 8;
         }
+    }
     // (a slot offset beyond the 16-bit field: second base registers for the upper half of the ring)
-    constexpr int A_SPAN = (RING - 1) * G_BYTES + 32 * TG * 2 + 4 * TG * 2;
-    constexpr bool A_TWO = A_SPAN >= 65536;
-    static_assert((RING - 1) * X_BYTES + 32 * TX * 2 < 65536, "x slot offsets fit the immediate");
-    static_assert(!A_TWO || ((RING - 3) * G_BYTES + 32 * TG * 2 + 4 * TG * 2 < 65536), "gy slot offsets");
-    unsigned a_base2[MF];
+    constexpr int A_IN = 32 * TG * 2 + 16 * TG * 2, B_IN = (KK_ROWS + H_ROWS) * TX * 2;     // largest offsets inside a slot
+    constexpr bool A_TWO = (RING - 1) * G_BYTES + A_IN >= 65536, B_TWO = (RING - 1) * X_BYTES + B_IN >= 65536;
+    static_assert(!A_TWO || ((RING - 3) * G_BYTES + A_IN < 65536 && G_BYTES + A_IN < 65536), "gy slot offsets");
+    static_assert(!B_TWO || ((RING - 3) * X_BYTES + B_IN < 65536 && X_BYTES + B_IN < 65536), "x slot offsets");
+    unsigned a_base2[MF], b_base2[3][NF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) a_base2[i] = a_base[i] + (A_TWO ? 2 * G_BYTES : 0);
+#pragma unroll
+    for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) b_base2[tp][j] = b_base[tp][j] + (B_TWO ? 2 * X_BYTES : 0);
 
     f32x4 acc[3][MF][NF];
 #pragma unroll
@@ -255,15 +269,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
         constexpr int KK = decltype(kk_c)::value, R = decltype(r_c)::value, SLOT = decltype(slot_c)::value;
         if constexpr (R < 2 * MF) {
             constexpr int i = R / 2, h = R % 2;
-            constexpr int OFF = ((A_TWO && SLOT >= 2) ? (SLOT - 2) * G_BYTES : SLOT * G_BYTES) + KK * 32 * TG * 2 + h * 4 * TG * 2;
+            constexpr int OFF = ((A_TWO && SLOT >= 2) ? (SLOT - 2) * G_BYTES : SLOT * G_BYTES) + KK * 32 * TG * 2 + h * 16 * TG * 2;
             const unsigned ab = (A_TWO && SLOT >= 2) ? a_base2[i] : a_base[i];
             if constexpr (h == 0) alo[KK][i] = lds_tr16<OFF>(ab);
             else ahi[KK][i] = lds_tr16<OFF>(ab);
         } else {
             constexpr int rr = R - 2 * MF, tp = rr / (2 * NF), j = (rr / 2) % NF, h = rr % 2;
-            constexpr int OFF = SLOT * X_BYTES + KK * 32 * TX * 2;
-            if constexpr (h == 0) blo[KK][tp][j] = lds_tr16<OFF>(b_base[0][tp][j]);
-            else bhi[KK][tp][j] = lds_tr16<OFF>(b_base[1][tp][j]);
+            constexpr int OFF = ((B_TWO && SLOT >= 2) ? (SLOT - 2) * X_BYTES : SLOT * X_BYTES) + KK * KK_ROWS * TX * 2 + h * H_ROWS * TX * 2;
+            const unsigned bb = (B_TWO && SLOT >= 2) ? b_base2[tp][j] : b_base[tp][j];
+            if constexpr (h == 0) blo[KK][tp][j] = lds_tr16<OFF>(bb);
+            else bhi[KK][tp][j] = lds_tr16<OFF>(bb);
         }
     };
     auto mfma_one = [&](auto kk_c, auto m_c) {
@@ -428,18 +443,19 @@ int g_kx3_ring = 0;     // 0 = default (4 where it fits), 3 / 4: A/B
 int g_kx3_var = -1;     // schedule variant (see the kernel); -1 = default (4 with a ring of 4)
 int g_kx3_blocks = 0;   // 0 = cost model, else target number of blocks
 
-template <int TG, int TX, int NWM, int NWN, int RING, int VAR>
+template <int TG, int TX, int NWM, int NWN, int RING, int VAR, int SEG>
 int kx3_launch_v(const Kx3Args& a, dim3 grid, hipStream_t s) {
-    constexpr int BYTES = RING * (64 * TG * 2 + kx_xrows(TX / 8) * TX * 2);
+    constexpr int BYTES = RING * kx_stage_bytes(TG, TX, SEG);
+    static_assert(BYTES <= 160 * 1024, "LDS");
     static TvPerDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kx3_kernel<TG, TX, NWM, NWN, RING, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        (void)hipFuncSetAttribute((const void*)wgrad_kx3_kernel<TG, TX, NWM, NWN, RING, VAR, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
     }
-    hipLaunchKernelGGL((wgrad_kx3_kernel<TG, TX, NWM, NWN, RING, VAR>), grid, dim3(512), BYTES, s, a);
+    hipLaunchKernelGGL((wgrad_kx3_kernel<TG, TX, NWM, NWN, RING, VAR, SEG>), grid, dim3(512), BYTES, s, a);
     return 0;
 }
 
-template <int TG, int TX, int NWM, int NWN, int RING>
+template <int TG, int TX, int NWM, int NWN, int RING, int SEG>
 int kx3_launch_r(Kx3Args a, hipStream_t s, bool plan_only) {
     const int tiles_co = a.c_out / TG;
     a.tiles_ci = a.c_in / TX;
@@ -481,25 +497,32 @@ int kx3_launch_r(Kx3Args a, hipStream_t s, bool plan_only) {
     a.xcd_order = (ny > 1 && xcd) ? 1 : 0;
     dim3 grid((unsigned)base, (unsigned)ny);
     if (a.xcd_order) grid = dim3((unsigned)(8 * base * ((ny + 7) / 8)), 1);
-    if constexpr (RING == 4) {   // (the lookahead RING - 2 variants need a ring of 4)
+    if constexpr (RING == 4 && SEG == 64) {   // (the lookahead RING - 2 variants need a ring of 4; A/B variants on the 64-pixel form only)
         switch (g_kx3_var < 0 ? 4 : g_kx3_var) {
-            case 1: return kx3_launch_v<TG, TX, NWM, NWN, RING, 1>(a, grid, s);
-            case 2: return kx3_launch_v<TG, TX, NWM, NWN, RING, 2>(a, grid, s);
-            case 3: return kx3_launch_v<TG, TX, NWM, NWN, RING, 3>(a, grid, s);
-            case 4: return kx3_launch_v<TG, TX, NWM, NWN, RING, 4>(a, grid, s);
+            case 1: return kx3_launch_v<TG, TX, NWM, NWN, RING, 1, SEG>(a, grid, s);
+            case 2: return kx3_launch_v<TG, TX, NWM, NWN, RING, 2, SEG>(a, grid, s);
+            case 3: return kx3_launch_v<TG, TX, NWM, NWN, RING, 3, SEG>(a, grid, s);
+            case 4: return kx3_launch_v<TG, TX, NWM, NWN, RING, 4, SEG>(a, grid, s);
             default: break;
         }
     }
-    return kx3_launch_v<TG, TX, NWM, NWN, RING, 0>(a, grid, s);
+    if (g_kx3_var != 0) return kx3_launch_v<TG, TX, NWM, NWN, RING, 4, SEG>(a, grid, s);    // schedule 4 works at any ring depth >= 3
+    return kx3_launch_v<TG, TX, NWM, NWN, RING, 0, SEG>(a, grid, s);
+}
+
+template <int TG, int TX, int NWM, int NWN, int SEG>
+int kx3_launch_s(const Kx3Args& a, hipStream_t s, bool plan_only) {
+    if constexpr (4 * kx_stage_bytes(TG, TX, SEG) <= 160 * 1024) {
+        if (g_kx3_ring != 3) return kx3_launch_r<TG, TX, NWM, NWN, 4, SEG>(a, s, plan_only);
+    }
+    return kx3_launch_r<TG, TX, NWM, NWN, 3, SEG>(a, s, plan_only);
 }
 
 template <int TG, int TX, int NWM, int NWN>
 int kx3_launch(const Kx3Args& a, hipStream_t s, bool plan_only) {
-    constexpr int STAGE = 64 * TG * 2 + kx_xrows(TX / 8) * TX * 2;
-    if constexpr (4 * STAGE <= 160 * 1024) {
-        if (g_kx3_ring != 3) return kx3_launch_r<TG, TX, NWM, NWN, 4>(a, s, plan_only);
-    }
-    return kx3_launch_r<TG, TX, NWM, NWN, 3>(a, s, plan_only);
+    if (a.w >= 64) return kx3_launch_s<TG, TX, NWM, NWN, 64>(a, s, plan_only);
+    if (a.w == 32) return kx3_launch_s<TG, TX, NWM, NWN, 32>(a, s, plan_only);
+    return kx3_launch_s<TG, TX, NWM, NWN, 16>(a, s, plan_only);
 }
 
 }  // namespace
@@ -507,11 +530,13 @@ int kx3_launch(const Kx3Args& a, hipStream_t s, bool plan_only) {
 // A/B hooks (tools/, tests): ring depth (0 = default, 3, 4), block target for the split-K choice (0 = cost model)
 extern "C" int tv_set_wgrad_kx3(int enable, int ring, int blocks);
 int g_kx3_enable = 1;
+int g_kx3_prefer128 = 0;
 extern "C" int tv_set_wgrad_kx3(int enable, int ring, int blocks) {   // ring = depth + 10 x schedule variant
     g_kx3_enable = enable;
     g_kx3_ring = ring % 10;
     g_kx3_var = ring >= 10 ? ring / 10 : (ring == 0 ? -1 : 0);     // a bare ring depth selects schedule 0 (A/B); 0 = all defaults
-    g_kx3_blocks = blocks;
+    g_kx3_blocks = blocks % 100000;
+    g_kx3_prefer128 = blocks / 100000;       // A/B: 2 = 192 x 96 x 3 tiles even where 128 x 128 x 3 divides the layer too
     return 0;
 }
 
@@ -524,7 +549,7 @@ int tv_wgrad_kx3_try(const tv_conv_desc* d, const void* x, const void* gy, float
     const long long M = (long long)d->batch * d->h_out * d->w_out;
     const long long xbytes = M * d->ldx * 2, gbytes = M * d->ldo * 2;
     const bool geo = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->up_shift == 0 && d->dil_mask == 0 &&
-                     d->h_in == d->h_out && d->w_in == d->w_out && wsh >= 6 && hwsh >= 6 &&
+                     d->h_in == d->h_out && d->w_in == d->w_out && wsh >= 4 && hwsh >= 6 &&
                      xbytes + (long long)(d->w_in + 1) * d->ldx * 2 < (1ll << 31) && gbytes < (1ll << 31);
     if (!geo) return -1;
     const bool t192 = d->c_out % 192 == 0 && d->c_in % 96 == 0;
@@ -536,6 +561,8 @@ int tv_wgrad_kx3_try(const tv_conv_desc* d, const void* x, const void* gy, float
     a.tiles_ci = 1; a.chunk_px = 0; a.hw_shift = hwsh; a.w_shift = wsh; a.plain = 0;
     a.xcd_order = 0; a.base = 1; a.ny = 1; a.accum = accum;
     a.x_bytes = (unsigned)xbytes;
-    if (t192) return kx3_launch<192, 96, 4, 2>(a, s, plan_only);
+    // both shapes divide the 384 / 768 / 1536-channel layers: the 128 x 128 x 3 tile measured 3-8 % faster there
+    // (tools/probes/ab_wgrad3.py: 384 @64 0.561 -> 0.544 ms, 768 @32 0.555 -> 0.541, 1536 @16 0.578 -> 0.534)
+    if (t192 && !(t128 && g_kx3_prefer128 != 2)) return kx3_launch<192, 96, 4, 2>(a, s, plan_only);
     return kx3_launch<128, 128, 2, 4>(a, s, plan_only);
 }

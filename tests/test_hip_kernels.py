@@ -182,7 +182,12 @@ WGRAD3_CASES = [
     (4, 64, 64, 192, 384, 0),     # two co tiles x two ci tiles; split-K chunks
     (5, 128, 128, 192, 192, 0),   # 81 920 pixels: split over many chunks, XCD-grouped order, ragged last chunk
     (2, 64, 64, 384, 384, 0),     # the Conv-FFN 3x3 of stage 2 (384 = 2 x 192 = 4 x 96)
-    (1, 16, 32, 192, 192, 0),     # W < 64: not this kernel's -- falls through to the single-tap kernel
+    (1, 16, 32, 192, 192, 0),     # W = 32: two 32-pixel segments per K-step (40 tile rows each)
+    (2, 16, 16, 192, 96, 0),      # W = 16: four 16-pixel segments per K-step (24 tile rows each), ring of 3
+    (3, 32, 32, 128, 256, 0),     # W = 32, 128-wide tiles, ring of 4
+    (2, 16, 16, 256, 128, 0),     # W = 16, 128-wide tiles: the x slots exceed the 16-bit offset field (second base registers)
+    (1, 8, 16, 128, 128, 3),      # W = 16, 8 rows: 128 pixels = 2 K-steps per image, ring of 3
+    (2, 8, 8, 192, 192, 0),       # W = 8: not this kernel's -- falls through to the single-tap kernel
     # the schedule variants (ring + 10 x variant, csrc/wgrad_kx3.hip): reads threaded into the MFMA phase, DMA pieces in either phase
     (2, 32, 128, 192, 192, 14), (2, 32, 128, 192, 192, 24), (2, 32, 128, 192, 192, 34), (2, 32, 128, 192, 192, 44),
     (3, 64, 64, 256, 128, 14), (3, 64, 64, 256, 128, 24), (3, 64, 64, 256, 128, 34), (3, 64, 64, 256, 128, 44),

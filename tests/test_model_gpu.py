@@ -719,7 +719,7 @@ def test_large_unit_gain_one_image_against_reference_golden(golden_dir):
           "(ref decoder alone %.4f)  recon vs reference %.4f (ref bf16 %.4f; not asserted)" %
           (e_mu, ref16["mu"], e_lv, ref16["logvar"], e_z, ref16["z"], e_path, ref16["decoder_alone"], e_rec, ref16["recon"]))
     assert e_mu < max(1e-2, 1.15 * ref16["mu"]) and e_lv < max(1e-2, 1.15 * ref16["logvar"]), (e_mu, e_lv)
-    assert e_path < max(1e-2, 1.25 * ref16["decoder_alone"]), (e_path, ref16["decoder_alone"])
+    assert e_path < max(1e-2, 1.1 * ref16["decoder_alone"]), (e_path, ref16["decoder_alone"])      # measured 1.00e-2 against 1.05e-2
 
 
 def test_giant_f16d32_train_step_fits_288gb():

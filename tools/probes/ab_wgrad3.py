@@ -23,9 +23,10 @@ def tm(fn, it=10):
 
 g = torch.Generator(device=dev).manual_seed(0)
 variants = [("single", (0, 0, 0)), ("kx3 r4", (1, 4, 0)), ("kx3 r3", (1, 3, 0))] + [(f"kx3 r4 v{v}", (1, 4 + 10 * v, 0)) for v in (1, 2, 3, 4)]
+variants += [("kx3 t192", (1, 0, 200000))]
 if len(sys.argv) > 2:
-    variants += [(f"kx3 r4 b{b}", (1, 4, int(b))) for b in sys.argv[2].split(",")]
-for (hw, Cc) in [(256, 192), (128, 192), (64, 384)]:
+    variants += [(f"kx3 b{b}", (1, 0, int(b))) for b in sys.argv[2].split(",")]
+for (hw, Cc) in [(256, 192), (128, 192), (64, 384), (32, 768), (16, 1536)]:
     x = torch.randn(mb, hw, hw, Cc, device=dev, generator=g).to(bf)
     gy = torch.randn(mb, hw, hw, Cc, device=dev, generator=g).to(bf)
     w = torch.zeros(Cc, 3, 3, Cc, device=dev)
