@@ -89,17 +89,54 @@ def time_dominant_kernel(mb: int, res: int, dev):
     # HBM bytes per launch: NOT measured in this run (PMC counters need their own rocprofv3 passes) -- read from the committed
     # summary of those passes over exactly this kernel and shape, scaled by the image count
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_dominant_kernel_pmc.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_dominant_kernel_pmc_all.json")
     if os.path.exists(pmc) and res == 256:
         with open(pmc) as f:
-            j = json.load(f)
+            j = json.load(f)["conv3x3_halo"]
         traffic = round(j["hbm_bytes_per_launch"] * mb / j["images"])
-        traffic_src = "profiles/r02_dominant_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --kernel-only`, gfx950 corrections applied; not measured inside this run)"
+        traffic_src = "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --kernel-only`, gfx950 corrections applied; not measured inside this run)"
     return {"bound": "mfma", "kernel": "conv3x3_halo_kernel<256,192,4,2,3,0> via tv_igemm_nt (conv3x3 192->192 @%dx%d, %d images; ping-pong main loop)" % (res, res, mb),
             "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": 2 * mb * res * res * C * 2 + 9 * C * C * 2}
+
+
+def time_wgrad_kernel(mb: int, res: int, dev):
+    """HIP-event timing of the weight gradient (+ bias gradient) of the same stage-0 ResBlock convolution (tv_wgrad_tn ->
+    wgrad_kx3_kernel): the largest weight-gradient kernel of the step (profiles/r03_rocprof_kernel_stats.csv)."""
+    from transvae.hip import ops
+    C = 192
+    x = torch.randn(mb, res, res, C, device=dev).to(torch.bfloat16)
+    gy = torch.randn(mb, res, res, C, device=dev).to(torch.bfloat16)
+    w = torch.zeros(C, 3, 3, C, device=dev)
+    geo = ops._Geo("c3s1", x, w)
+    dw, db = ops.conv_wgrad_alloc(geo, w, True, x, gy)
+    d = geo.fwd_desc(0)
+    for _ in range(10):
+        ops.wgrad_acc(d, x, gy, dw, db)
+    n = 30
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        ops.wgrad_acc(d, x, gy, dw, db)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flop = 2.0 * mb * res * res * C * 9 * C
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r03_dominant_kernel_pmc_all.json")
+    if os.path.exists(pmc) and res == 256:
+        with open(pmc) as f:
+            j = json.load(f).get("wgrad_kx3")
+        if j:
+            traffic = round(j["hbm_bytes_per_launch"] * mb / j["images"])
+            traffic_src = "profiles/r03_dominant_kernel_pmc_all.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --kernel-only`, gfx950 corrections applied; not measured inside this run)"
+    return {"bound": "mfma", "kernel": "wgrad_kx3_kernel<192,96,4,2,4,4,64> via tv_wgrad_tn_acc (weight + bias gradient of conv3x3 192->192 @%dx%d, %d images)" % (res, res, mb),
+            "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": 2 * mb * res * res * C * 2 + 9 * C * C * 4}
 
 
 def cpu_baseline(variant: str, res: int, threads: int, lr: float):
@@ -171,7 +208,9 @@ def main():
     args = ap.parse_args()
     if args.kernel_only:
         torch.cuda.set_device(0)
-        print(json.dumps(time_dominant_kernel(args.micro_batch, args.res, torch.device("cuda", 0))), flush=True)
+        r = time_dominant_kernel(args.micro_batch, args.res, torch.device("cuda", 0))
+        r["also"] = [time_wgrad_kernel(args.micro_batch, args.res, torch.device("cuda", 0))]
+        print(json.dumps(r), flush=True)
         return
 
     rank = int(os.environ.get("RANK", "0"))
@@ -316,6 +355,9 @@ def main():
             out["mfma_roofline_frac"] = round(ips * gf / 1e3 / world / PEAK_BF16_TFLOPS, 4)
         log("timing the dominant kernel")
         out["roofline"] = time_dominant_kernel(min(args.micro_batch, count), 256, dev)
+        # the dominant kernel BY TIME is the 3x3 convolution above (profiles/r03_rocprof_kernel_stats.csv: 15.5 % of the step);
+        # the largest weight-gradient kernel (9 %) is reported beside it
+        out["roofline"]["also"] = [time_wgrad_kernel(min(args.micro_batch, count), 256, dev)]
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle, 1 image) ...")
             del model, ddp, opt

@@ -17,6 +17,8 @@
 // MFMA work for the whole backward instead of 2.5x) -- the trade is recorded in DESIGN.md.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -131,6 +133,20 @@ __device__ __forceinline__ bf16x4 lds_tr16_imm(unsigned a) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(BYTES) : "memory");
     return r;
 }
+// Round 3: the ring stage is a compile-time constant too (the key / query loops are unrolled over their two stages), so the
+// stage base joins the immediate and a fragment read is `base register + offset field`, nothing else: the forward loop
+// spent 41 of its ~230 vector-ALU issue slots per 64-key block on v_add_u32 of the stage base (the loops are bound by
+// their vector ALU work: profiles/r02_attention.json).  abs_* = LDS byte address of (tile 0 of stage 0) + the lane's part.
+template <int IMM>
+__device__ __forceinline__ bf16x8 read_rows_imm(const char* abs_row) {
+    return *(const bf16x8*)(abs_row + IMM);
+}
+template <int IMM>
+__device__ __forceinline__ bf16x8 read_cols_imm(unsigned abs_lo, unsigned abs_hi) {
+    const bf16x4 lo = lds_tr16_imm<IMM>(abs_lo);
+    const bf16x4 hi = lds_tr16_imm<IMM>(abs_hi);
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
 template <int R0>
 __device__ __forceinline__ bf16x8 read_cols_at(const char* tile, int off, int offh) {
     const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)tile;
@@ -225,38 +241,52 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     int off_k[4], off_v[2], off_vh[2];
     rows_offsets(lane, off_k);
     cols_offsets<true>(lane, off_v, off_vh);
+    const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const char* abs_k[4];
+    unsigned abs_v[2], abs_vh[2];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) abs_k[st] = smem + off_k[st];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        abs_v[db] = smem_addr + off_v[db];
+        abs_vh[db] = smem_addr + off_vh[db];
+    }
     int vo_k[2], vo_v[2];
     stage_offsets<false>(vo_k, (int)ld, wave, lane);
     stage_offsets<true>(vo_v, (int)ld, wave, lane);
     const unsigned kv_bytes = stage_extent(p.N, (int)ld);
     stage_rows_buf(smem, kbase, kv_bytes, 0, (int)ld, vo_k, wave);
     stage_rows_buf(smem + KV_TILE, vbase, kv_bytes, 0, (int)ld, vo_v, wave);
-    for (int t = 0; t < nblk; ++t) {
+    // one 64-key block out of ring stage S (compile-time)
+    auto key_block = [&](int t, auto stage_c) {
+        constexpr int S = decltype(stage_c)::value;
+        constexpr int KB = S * 2 * KV_TILE, VB = KB + KV_TILE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nblk) {
-            char* nb = smem + ((t + 1) & 1) * 2 * KV_TILE;
+            char* nb = smem + (1 - S) * 2 * KV_TILE;
             stage_rows_buf(nb, kbase, kv_bytes, (t + 1) * 64, (int)ld, vo_k, wave);
             stage_rows_buf(nb + KV_TILE, vbase, kv_bytes, (t + 1) * 64, (int)ld, vo_v, wave);
         }
-        const char* kt_ = smem + (t & 1) * 2 * KV_TILE;
-        const char* vt_ = kt_ + KV_TILE;
         f32x16 s[2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
-#pragma unroll
-            for (int st = 0; st < 4; ++st) s[kt] = mfma32(read_rows_at(kt_, off_k[st], kt * 32), qf[st], s[kt]);
-        }
+        for (int i = 0; i < 16; ++i) s[0][i] = s[1][i] = 0.f;
+        s[0] = mfma32(read_rows_imm<KB>(abs_k[0]), qf[0], s[0]);
+        s[0] = mfma32(read_rows_imm<KB>(abs_k[1]), qf[1], s[0]);
+        s[0] = mfma32(read_rows_imm<KB>(abs_k[2]), qf[2], s[0]);
+        s[0] = mfma32(read_rows_imm<KB>(abs_k[3]), qf[3], s[0]);
+        s[1] = mfma32(read_rows_imm<KB + 32 * 128>(abs_k[0]), qf[0], s[1]);
+        s[1] = mfma32(read_rows_imm<KB + 32 * 128>(abs_k[1]), qf[1], s[1]);
+        s[1] = mfma32(read_rows_imm<KB + 32 * 128>(abs_k[2]), qf[2], s[1]);
+        s[1] = mfma32(read_rows_imm<KB + 32 * 128>(abs_k[3]), qf[3], s[1]);
         // V^T fragments of the whole 64-key block (transposed reads, asm): issued now, consumed after the softmax
         bf16x8 vfr[2][2][2];
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-            vfr[0][0][db] = read_cols_at<0>(vt_, off_v[db], off_vh[db]);
-            vfr[0][1][db] = read_cols_at<16>(vt_, off_v[db], off_vh[db]);
-            vfr[1][0][db] = read_cols_at<32>(vt_, off_v[db], off_vh[db]);
-            vfr[1][1][db] = read_cols_at<48>(vt_, off_v[db], off_vh[db]);
+            vfr[0][0][db] = read_cols_imm<VB + 0 * 128>(abs_v[db], abs_vh[db]);
+            vfr[0][1][db] = read_cols_imm<VB + 16 * 128>(abs_v[db], abs_vh[db]);
+            vfr[1][0][db] = read_cols_imm<VB + 32 * 128>(abs_v[db], abs_vh[db]);
+            vfr[1][1][db] = read_cols_imm<VB + 48 * 128>(abs_v[db], abs_vh[db]);
         }
         // online softmax over this lane's 32 keys (+ the other half-wave's 32); scores stay unscaled, the scale
         // rides in the exp2 FMA:  p = exp2(s*c2 - m*c2)
@@ -309,6 +339,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int db = 0; db < 2; ++db) ot[db] = mfma32(vfr[kt][ss][db], pf, ot[db]);
             }
+    };
+    for (int t = 0; t < nblk; t += 2) {
+        key_block(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nblk) key_block(t + 1, std::integral_constant<int, 1>{});
     }
     if (q_ok) {
         const float inv = 1.0f / l;
@@ -403,62 +437,76 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     int off_r[4], off_c[2], off_ch[2];
     rows_offsets(lane, off_r);
     cols_offsets<false>(lane, off_c, off_ch);
+    const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const char* abs_r[4];
+    unsigned abs_c[2], abs_ch[2];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) abs_r[st] = smem + off_r[st];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        abs_c[db] = smem_addr + off_c[db];
+        abs_ch[db] = smem_addr + off_ch[db];
+    }
 
     int vo_kv[2];
     stage_offsets<false>(vo_kv, (int)ld, wave, lane);
     const unsigned kv_bytes = stage_extent(p.N, (int)ld);
     stage_rows_buf(smem, kbase, kv_bytes, 0, (int)ld, vo_kv, wave);
     stage_rows_buf(smem + KV_TILE, vbase, kv_bytes, 0, (int)ld, vo_kv, wave);
-    for (int t = 0; t < nblk; ++t) {
+    // 32 keys (half KT of a 64-key block) out of ring stage S, both compile-time
+    auto half_block = [&](int t, auto stage_c, auto kt_c) {
+        constexpr int S = decltype(stage_c)::value, KT = decltype(kt_c)::value;
+        constexpr int KB = S * 2 * KV_TILE, VB = KB + KV_TILE, RO = KT * 32 * 128;
+        f32x16 s, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+        s = mfma32(read_rows_imm<KB + RO>(abs_r[0]), qf[0], s);
+        dp = mfma32(read_rows_imm<VB + RO>(abs_r[0]), gf[0], dp);
+        s = mfma32(read_rows_imm<KB + RO>(abs_r[1]), qf[1], s);
+        dp = mfma32(read_rows_imm<VB + RO>(abs_r[1]), gf[1], dp);
+        s = mfma32(read_rows_imm<KB + RO>(abs_r[2]), qf[2], s);
+        dp = mfma32(read_rows_imm<VB + RO>(abs_r[2]), gf[2], dp);
+        s = mfma32(read_rows_imm<KB + RO>(abs_r[3]), qf[3], s);
+        dp = mfma32(read_rows_imm<VB + RO>(abs_r[3]), gf[3], dp);
+        bf16x8 kfr[2][2];   // K^T fragments (transposed asm reads): in flight during the exponentials
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            kfr[0][db] = read_cols_imm<KB + RO>(abs_c[db], abs_ch[db]);
+            kfr[1][db] = read_cols_imm<KB + RO + 16 * 128>(abs_c[db], abs_ch[db]);
+        }
+        const int kv0 = t * 64;
+        if (kv0 + 64 > p.N) {   // ragged last block: keys >= N must not contribute (P = 0): push their score to -inf
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + KT * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (key >= p.N) s[r] = -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = fexp2(fmaf(s[r], c2, nl)) * (dp[r] + nd);  // dS^T (without the factor `scale`)
+        lds_wait_all();
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const bf16x8 df = pack_acc(s, ss);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) dqt[db] = mfma32(kfr[ss][db], df, dqt[db]);
+        }
+    };
+    auto key_block = [&](int t, auto stage_c) {
+        constexpr int S = decltype(stage_c)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nblk) {
-            char* nb = smem + ((t + 1) & 1) * 2 * KV_TILE;
+            char* nb = smem + (1 - S) * 2 * KV_TILE;
             stage_rows_buf(nb, kbase, kv_bytes, (t + 1) * 64, (int)ld, vo_kv, wave);
             stage_rows_buf(nb + KV_TILE, vbase, kv_bytes, (t + 1) * 64, (int)ld, vo_kv, wave);
         }
-        const char* kt_ = smem + (t & 1) * 2 * KV_TILE;
-        const char* vt_ = kt_ + KV_TILE;
-        const int kv0 = t * 64;
-        const bool partial = kv0 + 64 > p.N;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            f32x16 s, dp;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                s = mfma32(read_rows_at(kt_, off_r[st], kt * 32), qf[st], s);
-                dp = mfma32(read_rows_at(vt_, off_r[st], kt * 32), gf[st], dp);
-            }
-            bf16x8 kfr[2][2];   // K^T fragments (transposed asm reads): in flight during the exponentials
-#pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                if (kt == 0) {
-                    kfr[0][db] = read_cols_at<0>(kt_, off_c[db], off_ch[db]);
-                    kfr[1][db] = read_cols_at<16>(kt_, off_c[db], off_ch[db]);
-                } else {
-                    kfr[0][db] = read_cols_at<32>(kt_, off_c[db], off_ch[db]);
-                    kfr[1][db] = read_cols_at<48>(kt_, off_c[db], off_ch[db]);
-                }
-            }
-            if (partial) {   // ragged last block: keys >= N must not contribute (P = 0): push their score to -inf
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kv0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (key >= p.N) s[r] = -INFINITY;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = fexp2(fmaf(s[r], c2, nl)) * (dp[r] + nd);  // dS^T (without the factor `scale`)
-            lds_wait_all();
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                const bf16x8 df = pack_acc(s, ss);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) dqt[db] = mfma32(kfr[ss][db], df, dqt[db]);
-            }
-        }
+        half_block(t, stage_c, std::integral_constant<int, 0>{});
+        half_block(t, stage_c, std::integral_constant<int, 1>{});
+    };
+    for (int t = 0; t < nblk; t += 2) {
+        key_block(t, std::integral_constant<int, 0>{});
+        if (t + 1 < nblk) key_block(t + 1, std::integral_constant<int, 1>{});
     }
     if (q_ok) {
         bf16* row = p.out + ((size_t)b * p.N + qi) * ld + head * 64;  // q third of dqkv
@@ -534,36 +582,52 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         }
     };
 
+    const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const char* abs_r[4];
+    unsigned abs_c[2], abs_ch[2];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) abs_r[st] = smem + off_r[st];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        abs_c[db] = smem_addr + off_c[db];
+        abs_ch[db] = smem_addr + off_ch[db];
+    }
+    const char* abs_st = smem + 2 * QT_TILE + 16 * h;      // this lane half's part of the lse / delta rows
     stage(0, smem);
-    for (int t = 0; t < ntile; ++t) {
+    // one 32-query tile out of ring stage S (compile-time)
+    auto query_tile = [&](int t, auto stage_c) {
+        constexpr int S = decltype(stage_c)::value;
+        constexpr int QB = S * DKV_STAGE, GB = QB + QT_TILE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < ntile) stage(t + 1, smem + ((t + 1) & 1) * DKV_STAGE);
-        const char* qt_ = smem + (t & 1) * DKV_STAGE;
-        const char* gt_ = qt_ + QT_TILE;
-        const float* st_lse = (const float*)(qt_ + 2 * QT_TILE);
-        const float* st_del = st_lse + 32;
+        if (t + 1 < ntile) stage(t + 1, smem + (1 - S) * DKV_STAGE);
         f32x16 s, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;   // (inline-constant accumulator start: see attn_bwd_dq_kernel)
         f32x4 nl[4], nd[4];                                // accumulator rows (queries) 8g+4h+{0..3}
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            nl[g] = *(const f32x4*)(st_lse + 8 * g + 4 * h);
-            nd[g] = *(const f32x4*)(st_del + 8 * g + 4 * h);
-        }
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            s = mfma32(read_rows_at(qt_, off_r[st], 0), kf[st], s);
-            dp = mfma32(read_rows_at(gt_, off_r[st], 0), vf[st], dp);
-        }
+        nl[0] = *(const f32x4*)(abs_st + QB + 0);
+        nl[1] = *(const f32x4*)(abs_st + QB + 32);
+        nl[2] = *(const f32x4*)(abs_st + QB + 64);
+        nl[3] = *(const f32x4*)(abs_st + QB + 96);
+        nd[0] = *(const f32x4*)(abs_st + QB + 128 + 0);
+        nd[1] = *(const f32x4*)(abs_st + QB + 128 + 32);
+        nd[2] = *(const f32x4*)(abs_st + QB + 128 + 64);
+        nd[3] = *(const f32x4*)(abs_st + QB + 128 + 96);
+        s = mfma32(read_rows_imm<QB>(abs_r[0]), kf[0], s);
+        dp = mfma32(read_rows_imm<GB>(abs_r[0]), vf[0], dp);
+        s = mfma32(read_rows_imm<QB>(abs_r[1]), kf[1], s);
+        dp = mfma32(read_rows_imm<GB>(abs_r[1]), vf[1], dp);
+        s = mfma32(read_rows_imm<QB>(abs_r[2]), kf[2], s);
+        dp = mfma32(read_rows_imm<GB>(abs_r[2]), vf[2], dp);
+        s = mfma32(read_rows_imm<QB>(abs_r[3]), kf[3], s);
+        dp = mfma32(read_rows_imm<GB>(abs_r[3]), vf[3], dp);
         bf16x8 gfr[2][2], qfr[2][2];   // dO^T and Q^T fragments (transposed asm reads)
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
-            gfr[0][db] = read_cols_at<0>(gt_, off_c[db], off_ch[db]);
-            gfr[1][db] = read_cols_at<16>(gt_, off_c[db], off_ch[db]);
-            qfr[0][db] = read_cols_at<0>(qt_, off_c[db], off_ch[db]);
-            qfr[1][db] = read_cols_at<16>(qt_, off_c[db], off_ch[db]);
+            gfr[0][db] = read_cols_imm<GB>(abs_c[db], abs_ch[db]);
+            gfr[1][db] = read_cols_imm<GB + 16 * 128>(abs_c[db], abs_ch[db]);
+            qfr[0][db] = read_cols_imm<QB>(abs_c[db], abs_ch[db]);
+            qfr[1][db] = read_cols_imm<QB + 16 * 128>(abs_c[db], abs_ch[db]);
         }
         // queries beyond N have Q = dO = 0, lse = delta = 0  =>  P = 1, dS = 0, and dO^T P adds 0
 #pragma unroll
@@ -583,6 +647,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
                 dkt[db] = mfma32(qfr[ss][db], df, dkt[db]);
             }
         }
+    };
+    for (int t = 0; t < ntile; t += 2) {
+        query_tile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < ntile) query_tile(t + 1, std::integral_constant<int, 1>{});
     }
     if (k_ok) {
         bf16* krow = p.out + ((size_t)b * p.N + ki) * ld + C + head * 64;

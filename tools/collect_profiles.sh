@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round profiles on the GPU box (one gpurun call):  tools/collect_profiles.sh r02
+# Round profiles on the GPU box (one gpurun call):  tools/collect_profiles.sh r03
 #   kernel-trace stats of the bench and of the dominant kernel alone, PMC passes (HBM bytes, MFMA busy) in their own runs,
 #   GEMM sweep, attention shapes.  Raw rocprofv3 output stays under gpurun_out/ (scratch); the summaries land in
 #   gpurun_out/profiles_<round>/ -- copy them into profiles/ (tracked).
 set -e
-R=${1:-r02}
+R=${1:-r03}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/profiles_$R; mkdir -p $OUT
@@ -24,6 +24,7 @@ python3 tools/probes/pmc_summary.py $OUT/${R}_dominant_kernel_pmc_raw.json \
     fetch=$(find $P/pmc_fetch -name "*counter_collection.csv" | head -1) \
     write=$(find $P/pmc_write -name "*counter_collection.csv" | head -1) \
     sq=$(find $P/pmc_sq -name "*counter_collection.csv" | head -1)
+python3 tools/probes/pmc_derive.py $OUT/${R}_dominant_kernel_pmc_raw.json $OUT/${R}_dominant_kernel_pmc_all.json images=64 note="bench.py --kernel-only --micro-batch 64: conv3x3 192->192 @256x256 forward (conv3x3_halo) and its weight + bias gradient (wgrad_kx3), 40 dispatches each incl. warm-up"
 echo "[4] attention: per-shape rates and MFMA busy"
 python3 tools/attn_bench.py 64 > $OUT/${R}_attention_shapes.txt 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $P/pmc_attn -o a -- python3 tools/attn_bench.py 64 > /dev/null 2>&1
@@ -40,5 +41,7 @@ python3 tools/probes/pmc_summary.py $OUT/${R}_gemm_kernels_pmc_raw.json \
     sq=$(find $P/pmc_gemm -name "*counter_collection.csv" | head -1) \
     fetch=$(find $P/pmc_gemm_f -name "*counter_collection.csv" | head -1) \
     write=$(find $P/pmc_gemm_w -name "*counter_collection.csv" | head -1)
+python3 tools/probes/pmc_derive.py $OUT/${R}_gemm_kernels_pmc_raw.json $OUT/${R}_gemm_kernels_pmc.json images=64 note="tools/gemm_sweep.py --mb 64 --only res192@256: forward + data gradient (conv3x3_halo), weight gradient without bias (wgrad_kx3)"
+python3 tools/probes/pmc_derive.py $OUT/${R}_attention_pmc_raw.json $OUT/${R}_attention_pmc.json images=64
 rm -rf $P
 ls -la $OUT

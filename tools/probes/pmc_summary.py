@@ -3,7 +3,7 @@ the raw CSVs are too large to travel).  usage: pmc_summary.py OUT.json NAME=coun
 import collections, csv, json, sys
 
 def fam(n):
-    for key in ("conv3x3_halo", "igemm_nt", "wgrad_tn", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_delta", "gn_silu_fwd",
+    for key in ("conv3x3_halo", "igemm_nt", "wgrad_kx3", "wgrad_tn", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_delta", "gn_silu_fwd",
                 "gn_silu_bwd_apply", "gn_silu_bwd_reduce", "gn_stats", "gn_finalize", "rownorm_fwd", "rownorm_bwd", "rope_qk", "pack_weight"):
         if key in n:
             return key
