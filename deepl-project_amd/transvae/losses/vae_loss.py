@@ -72,19 +72,26 @@ def fused_l1_kl(reconstruction: torch.Tensor, target: torch.Tensor, mu: torch.Te
 
 
 class TransVAELoss(nn.Module):
-    def __init__(self, l1_weight: float = 1.0, lpips_weight: float = 0.0, kl_weight: float = 1e-8, vf_weight: float = 0.0,
-                 gan_weight: float = 0.0, use_gan: bool = False, sigmoid_recon: bool = False, kl_mean: bool = False,
+    def __init__(self, l1_weight: float = 1.0, lpips_weight: float = 1.0, kl_weight: float = 1e-8, vf_weight: float = 0.1,
+                 gan_weight: float = 0.05, use_gan: bool = False, sigmoid_recon: bool = False, kl_mean: bool = False,
                  logvar_clip: Optional[Tuple[float, float]] = None):
+        """Defaults are the reference's (R/transvae/losses/vae_loss.py:31-38: lpips 1.0, vf 0.1, gan 0.05, use_gan False), so
+        `TransVAELoss()` cannot silently mean something else here: the LPIPS term (always on in the reference, VGG weights
+        from the network) is outside this build and a non-zero lpips_weight RAISES -- pass lpips_weight=0 for the closed-form
+        terms.  The VF and GAN terms only exist in the reference when its forward() is handed a DINOv2 model / a discriminator
+        (vae_loss.py:99-112); handing one to this forward() raises as well."""
         super().__init__()
-        if lpips_weight != 0.0 or vf_weight != 0.0 or use_gan:
-            raise ValueError("TransVAELoss (HIP path): LPIPS / VF / GAN terms need external networks (VGG, DINOv2, a discriminator) "
-                             "and are outside this build; construct with lpips_weight=0, vf_weight=0, use_gan=False and add "
-                             "those terms with the reference's own modules")
+        if lpips_weight != 0.0:
+            raise ValueError("TransVAELoss (HIP path): the LPIPS term needs the external VGG network (lpips package) and is outside "
+                             "this build; construct with lpips_weight=0 (closed-form L1 + KL) and add LPIPS with the reference's own module")
         self.l1_weight, self.lpips_weight, self.kl_weight = l1_weight, lpips_weight, kl_weight
         self.vf_weight, self.gan_weight, self.use_gan = vf_weight, gan_weight, use_gan
         self.sigmoid_recon, self.kl_mean, self.logvar_clip = sigmoid_recon, kl_mean, logvar_clip
 
     def forward(self, reconstruction, target, mu, logvar, discriminator=None, dinov2=None) -> dict:
+        if (dinov2 is not None and self.vf_weight > 0) or (self.use_gan and discriminator is not None):
+            raise ValueError("TransVAELoss (HIP path): VF (DINOv2) and GAN (discriminator) terms are outside this build; call "
+                             "without dinov2 / discriminator and add those terms with the reference's own modules")
         out = fused_l1_kl(reconstruction, target, mu, logvar, self.l1_weight, self.kl_weight, self.kl_mean, self.sigmoid_recon,
                           self.logvar_clip)
         return {"l1": out[0], "kl": out[1], "total": out[2]}

@@ -516,7 +516,7 @@ def test_fused_l1_kl_loss_matches_the_reference_formulas(variant):
         kl = -0.5 * torch.sum(1 + lv - m64.pow(2) - lv.exp()) / (mu.shape[0] * mu.shape[2] * mu.shape[3])
     total = 1.0 * l1 + 1e-3 * kl
     total.backward()
-    loss_fn = TransVAELoss(l1_weight=1.0, kl_weight=1e-3, sigmoid_recon=patched, kl_mean=patched, logvar_clip=(-30.0, 20.0))
+    loss_fn = TransVAELoss(l1_weight=1.0, lpips_weight=0.0, kl_weight=1e-3, sigmoid_recon=patched, kl_mean=patched, logvar_clip=(-30.0, 20.0))
     rd, md, ld = (t.to(DEV).requires_grad_(True) for t in (recon, mu, logvar))
     out = loss_fn(rd, target.to(DEV), md, ld)
     assert set(out) == {"l1", "kl", "total"}
@@ -526,8 +526,16 @@ def test_fused_l1_kl_loss_matches_the_reference_formulas(variant):
     out["total"].backward()
     for got, ref in ((rd.grad, r64.grad), (md.grad, m64.grad), (ld.grad, l64.grad)):
         assert float((got.cpu().double() - ref).norm()) < 1e-5 * float(ref.norm()) + 1e-12
-    with pytest.raises(ValueError, match="external networks"):
+    # the reference's defaults (vae_loss.py:31-38: lpips 1.0, vf 0.1, gan 0.05) are kept: what cannot be computed here raises
+    with pytest.raises(ValueError, match="LPIPS"):
+        TransVAELoss()
+    with pytest.raises(ValueError, match="LPIPS"):
         TransVAELoss(lpips_weight=1.0)
+    with pytest.raises(ValueError, match="VF"):
+        loss_fn(rd, target.to(DEV), md, ld, dinov2=torch.nn.Identity())
+    import inspect
+    sig = inspect.signature(TransVAELoss.__init__).parameters
+    assert (sig["lpips_weight"].default, sig["vf_weight"].default, sig["gan_weight"].default, sig["use_gan"].default) == (1.0, 0.1, 0.05, False)
 
 
 def test_resume_from_a_reference_written_checkpoint(golden_dir):
