@@ -97,15 +97,18 @@ __device__ __forceinline__ void static_for(F&& f) {
 // (group 1).  Reads threaded into the MFMA phase make a group read K-step t while the other group is already in load phase
 // t + 1, so a piece issued in a LOAD phase may then only overwrite the slot of step t - 2 (lookahead RING - 2); pieces issued
 // in an MFMA phase may always overwrite the slot of step t - 1.
-template <int TG, int TX, int NWM, int NWN, int RING, int VAR, int SEG>
+// TAPS = 3: the kx-triple of a 3x3 layer.  TAPS = 1: the same loop for a 1x1 / linear layer (one tap, no neighbour rows, no ky):
+// what remains of the design there is the ping-pong schedule and the immediate-offset reads.
+template <int TG, int TX, int NWM, int NWN, int RING, int VAR, int SEG, int TAPS = 3>
 __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     constexpr int NW = 8, BKP = 64;
     static_assert(NWM * NWN == NW, "8 waves");
     static_assert(SEG == 16 || SEG == 32 || SEG == 64, "segment = min(image width, 64)");
+    static_assert(TAPS == 3 || (TAPS == 1 && SEG == 64), "one tap: 64 consecutive rows per K-step");
     constexpr int CG = TG / 8, CX = TX / 8;
-    constexpr int NSEG = BKP / SEG, SS = kx_seg_stride(SEG);   // segments per K-step, tile rows per segment
+    constexpr int NSEG = BKP / SEG, SS = TAPS == 1 ? 64 : kx_seg_stride(SEG);   // segments per K-step, tile rows per segment
     constexpr int G_PIECES = BKP * CG / 64;                    // 1 KiB pieces of the gy tile
-    constexpr int X_PIECES = kx_x_pieces(SEG, CX);             // ... of the x tile
+    constexpr int X_PIECES = TAPS == 1 ? CX : kx_x_pieces(SEG, CX);             // ... of the x tile
     static_assert(G_PIECES % NW == 0, "gy pieces divide over the waves");
     constexpr int G_IT = G_PIECES / NW, X_IT = (X_PIECES + NW - 1) / NW, P_IT = G_IT + X_IT;
     constexpr int XR = X_PIECES % NW;                          // waves below XR issue X_IT x pieces, the others X_IT - 1 (XR != 0)
@@ -138,15 +141,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     }
     const int ci_tile = bx % p.tiles_ci;
     bx /= p.tiles_ci;
-    const int ky = bx % 3;
-    const int co_tile = bx / 3;
+    const int ky = TAPS == 3 ? bx % 3 : 0;
+    const int co_tile = TAPS == 3 ? bx / 3 : bx;
     const int co0 = co_tile * TG, ci0 = ci_tile * TX;
     const int p_begin = chunk_id * p.chunk_px;
     const int p_end = min(p.M, p_begin + p.chunk_px);
     const int nsteps = (p_end - p_begin) / BKP;                // (M and the chunk size are multiples of 64: host)
     if (nsteps <= 0) return;
     const int w = p.w, hw = p.h * p.w;
-    const int dty = ky - 1;
+    const int dty = TAPS == 3 ? ky - 1 : 0;
 
     // ---- staging bookkeeping (fixed per thread) ---------------------------------------------------------------------------
     int g_voff[G_IT];
@@ -163,11 +166,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
         const int id = (it * NW + wave) * 64 + lane;
         const int R = id / CX, sl = id - R * CX;
         const int sg = R / SS, o = R - sg * SS;                                  // segment, row inside it (0 = left neighbour)
-        const int need = o == 0 ? 2 : (o == SEG + 1 ? 4 : (o > SEG + 1 ? 0 : 1));
+        const int need = TAPS == 1 ? 1 : (o == 0 ? 2 : (o == SEG + 1 ? 4 : (o > SEG + 1 ? 0 : 1)));
         x_need[it] = sg < NSEG ? need << (3 * sg) : 0;
-        x_voff[it] = ((sg * SEG + o) * p.ldx + ci0 + kx_swz<TX>(sl, R) * 8) * 2;   // relative to pixel (pz + dty w - 1)
+        x_voff[it] = ((sg * SEG + o) * p.ldx + ci0 + kx_swz<TX>(sl, R) * 8) * 2;   // relative to pixel (pz + dty w - 1); one tap: to pixel pz
     }
-    const long long dshift = ((long long)dty * w - 1) * p.ldx;                 // elements
+    const long long dshift = TAPS == 1 ? 0 : ((long long)dty * w - 1) * p.ldx;                 // elements
     const bf16* xb = p.x + dshift;
     const unsigned xb_bytes = (unsigned)((long long)p.x_bytes - dshift * 2);
     const unsigned g_bytes = (unsigned)((long long)p_end * p.ldo * 2);
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     // piece iteration IT of K-step `step` into ring slot `slot`: IT < G_IT a gy piece, else an x piece
     auto x_have = [&](int step) {   // one scalar mask per step against one per-lane bit: no divergent control flow around the DMA issue
         int have = 0;
+        if constexpr (TAPS == 1) return 1;     // (rows beyond the tensor read as zeros through the descriptor's extent)
 #pragma unroll
         for (int sg = 0; sg < NSEG; ++sg) {
             const int pz = p_begin + step * BKP + sg * SEG;
@@ -212,9 +216,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
         const int col = wm * WTG + i * 16 + 4 * pp;
         a_base[i] = smem_addr + r * (TG * 2) + kx_swz<TG>(col >> 3, r) * 16 + (pp & 1) * 8;
     }
-    unsigned b_base[3][NF];
+    unsigned b_base[TAPS][NF];
 #pragma unroll
-    for (int tp = 0; tp < 3; ++tp) {
+    for (int tp = 0; tp < TAPS; ++tp) {
         const int R = 4 * g + q + tp;                 // tile row of tap kx = tp for pixel 4g + q (row 0 of a segment = left neighbour)
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
@@ -227,17 +231,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     constexpr bool A_TWO = (RING - 1) * G_BYTES + A_IN >= 65536, B_TWO = (RING - 1) * X_BYTES + B_IN >= 65536;
     static_assert(!A_TWO || ((RING - 3) * G_BYTES + A_IN < 65536 && G_BYTES + A_IN < 65536), "gy slot offsets");
     static_assert(!B_TWO || ((RING - 3) * X_BYTES + B_IN < 65536 && X_BYTES + B_IN < 65536), "x slot offsets");
-    unsigned a_base2[MF], b_base2[3][NF];
+    unsigned a_base2[MF], b_base2[TAPS][NF];
 #pragma unroll
     for (int i = 0; i < MF; ++i) a_base2[i] = a_base[i] + (A_TWO ? 2 * G_BYTES : 0);
 #pragma unroll
-    for (int tp = 0; tp < 3; ++tp)
+    for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
         for (int j = 0; j < NF; ++j) b_base2[tp][j] = b_base[tp][j] + (B_TWO ? 2 * X_BYTES : 0);
 
-    f32x4 acc[3][MF][NF];
+    f32x4 acc[TAPS][MF][NF];
 #pragma unroll
-    for (int tp = 0; tp < 3; ++tp)
+    for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     // the launch (one block per CU), ran 25-30 % longer than the bias-free kernel.  Every block ADDS its share into dbias
     // with atomics (single-chunk launches too): the caller passes a zeroed dbias or one that holds a running sum.
     const bool do_bias = p.dbias != nullptr;
-    const int nshare = 3 * p.tiles_ci;
+    const int nshare = TAPS * p.tiles_ci;
     int bias_ctr = ky * p.tiles_ci + ci_tile;     // steps until this block's next turn
     bool own = false, own_prev = false;
     constexpr int NB = (MF + NWN - 1) / NWN;
@@ -260,11 +264,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     for (int k = 0; k < NB; ++k) bsum[k] = 0.f;
 
     auto join = [](bf16x4 lo, bf16x4 hi) { return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
-    bf16x4 alo[2][MF], ahi[2][MF], blo[2][3][NF], bhi[2][3][NF];
+    bf16x4 alo[2][MF], ahi[2][MF], blo[2][TAPS][NF], bhi[2][TAPS][NF];
     const int grp = wave >> 2;
 
     // read number R of the NR = 2 MF + 6 NF transposing reads of 32-pixel half KK of ring slot SLOT
-    constexpr int NR = 2 * MF + 6 * NF, NM = 3 * MF * NF;
+    constexpr int NR = 2 * MF + 2 * TAPS * NF, NM = TAPS * MF * NF;
     auto frag_read = [&](auto kk_c, auto r_c, auto slot_c) {
         constexpr int KK = decltype(kk_c)::value, R = decltype(r_c)::value, SLOT = decltype(slot_c)::value;
         if constexpr (R < 2 * MF) {
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     };
     auto mfma_one = [&](auto kk_c, auto m_c) {
         constexpr int KK = decltype(kk_c)::value, M = decltype(m_c)::value;
-        constexpr int i = M / (3 * NF), tp = (M / NF) % 3, j = M % NF;
+        constexpr int i = M / (TAPS * NF), tp = (M / NF) % TAPS, j = M % NF;
         acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join(alo[KK][i], ahi[KK][i]), join(blo[KK][tp][j], bhi[KK][tp][j]), acc[tp][i][j], 0, 0, 0);
     };
     auto bias_add = [&](auto kk_c) {
@@ -407,15 +411,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_kx3_kernel(const Kx3Args p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
 
     // ---- fp32 results into dw[co][ky*3 + kx][ci]; D layout: row = (lane>>4)*4 + reg (co), col = lane&15 (ci)
-    const size_t ldw = (size_t)9 * p.c_in;
+    const size_t ldw = (size_t)(TAPS * TAPS) * p.c_in;
 #pragma unroll
     for (int i = 0; i < MF; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = co0 + wm * WTG + i * 16 + g * 4 + r;
 #pragma unroll
-            for (int tp = 0; tp < 3; ++tp) {
-                float* rowp = p.dw + (size_t)co * ldw + (size_t)(ky * 3 + tp) * p.c_in;
+            for (int tp = 0; tp < TAPS; ++tp) {
+                float* rowp = p.dw + (size_t)co * ldw + (size_t)(ky * TAPS + tp) * p.c_in;
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {
                     const int ci = ci0 + wn * WTX + j * 16 + (lane & 15);
@@ -443,27 +447,27 @@ int g_kx3_ring = 0;     // 0 = default (4 where it fits), 3 / 4: A/B
 int g_kx3_var = -1;     // schedule variant (see the kernel); -1 = default (4 with a ring of 4)
 int g_kx3_blocks = 0;   // 0 = cost model, else target number of blocks
 
-template <int TG, int TX, int NWM, int NWN, int RING, int VAR, int SEG>
+template <int TG, int TX, int NWM, int NWN, int RING, int VAR, int SEG, int TAPS = 3>
 int kx3_launch_v(const Kx3Args& a, dim3 grid, hipStream_t s) {
-    constexpr int BYTES = RING * kx_stage_bytes(TG, TX, SEG);
+    constexpr int BYTES = RING * (TAPS == 1 ? 64 * (TG + TX) * 2 : kx_stage_bytes(TG, TX, SEG));
     static_assert(BYTES <= 160 * 1024, "LDS");
     static TvPerDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)wgrad_kx3_kernel<TG, TX, NWM, NWN, RING, VAR, SEG>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        (void)hipFuncSetAttribute((const void*)wgrad_kx3_kernel<TG, TX, NWM, NWN, RING, VAR, SEG, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
     }
-    hipLaunchKernelGGL((wgrad_kx3_kernel<TG, TX, NWM, NWN, RING, VAR, SEG>), grid, dim3(512), BYTES, s, a);
+    hipLaunchKernelGGL((wgrad_kx3_kernel<TG, TX, NWM, NWN, RING, VAR, SEG, TAPS>), grid, dim3(512), BYTES, s, a);
     return 0;
 }
 
-template <int TG, int TX, int NWM, int NWN, int RING, int SEG>
+template <int TG, int TX, int NWM, int NWN, int RING, int SEG, int TAPS = 3>
 int kx3_launch_r(Kx3Args a, hipStream_t s, bool plan_only) {
     const int tiles_co = a.c_out / TG;
     a.tiles_ci = a.c_in / TX;
-    const long long base = (long long)tiles_co * 3 * a.tiles_ci;
+    const long long base = (long long)tiles_co * TAPS * a.tiles_ci;
     // split-K over pixel chunks: one block per CU; with the XCD-grouped order a chunk's `base` tiles share an XCD (32 CUs).
     // minimise  rounds x (pixels per block) x t_pixel  +  atomic bytes / 1.3 TB/s  (MI355X_MICROARCH "Global float atomics")
-    const double t_px = 2.0 * TG * TX * 3 * 256.0 / 1200e12;
-    const double tile_bytes = 4.0 * TG * TX * 3;
+    const double t_px = 2.0 * TG * TX * TAPS * 256.0 / 1200e12;
+    const double tile_bytes = 4.0 * TG * TX * TAPS;
     long long split = 1;
     bool xcd = false;
     double best = 1e30;
@@ -497,7 +501,10 @@ int kx3_launch_r(Kx3Args a, hipStream_t s, bool plan_only) {
     a.xcd_order = (ny > 1 && xcd) ? 1 : 0;
     dim3 grid((unsigned)base, (unsigned)ny);
     if (a.xcd_order) grid = dim3((unsigned)(8 * base * ((ny + 7) / 8)), 1);
-    if constexpr (RING == 4 && SEG == 64) {   // (the lookahead RING - 2 variants need a ring of 4; A/B variants on the 64-pixel form only)
+    if constexpr (TAPS == 1) {
+        if (g_kx3_var == 0) return kx3_launch_v<TG, TX, NWM, NWN, RING, 0, SEG, 1>(a, grid, s);      // (A/B)
+        return kx3_launch_v<TG, TX, NWM, NWN, RING, 4, SEG, 1>(a, grid, s);
+    } else if constexpr (RING == 4 && SEG == 64) {   // (the lookahead RING - 2 variants need a ring of 4; A/B variants on the 64-pixel form only)
         switch (g_kx3_var < 0 ? 4 : g_kx3_var) {
             case 1: return kx3_launch_v<TG, TX, NWM, NWN, RING, 1, SEG>(a, grid, s);
             case 2: return kx3_launch_v<TG, TX, NWM, NWN, RING, 2, SEG>(a, grid, s);
@@ -529,7 +536,7 @@ int kx3_launch(const Kx3Args& a, hipStream_t s, bool plan_only) {
 
 // A/B hooks (tools/, tests): ring depth (0 = default, 3, 4), block target for the split-K choice (0 = cost model)
 extern "C" int tv_set_wgrad_kx3(int enable, int ring, int blocks);
-int g_kx3_enable = 1;
+int g_kx3_enable = 2;     // 0 = off, 1 = 3x3 / stride-1 layers, 2 = linear / 1x1 layers too (one-tap instantiation); + 10 t: tile A/B
 int g_kx3_prefer128 = 0;
 extern "C" int tv_set_wgrad_kx3(int enable, int ring, int blocks) {   // ring = depth + 10 x schedule variant
     g_kx3_enable = enable;
@@ -545,6 +552,29 @@ extern "C" int tv_set_wgrad_kx3(int enable, int ring, int blocks) {   // ring = 
 int tv_wgrad_kx3_try(const tv_conv_desc* d, const void* x, const void* gy, float* dw, float* dbias, hipStream_t s, bool plan_only, int accum) {
     if (!g_kx3_enable) return -1;
     auto log2_exact = [](int v) { int sh = 0; while ((1 << sh) < v) ++sh; return ((1 << sh) == v) ? sh : -1; };
+    // linear / 1x1 layers through the one-tap instantiation: nothing to share between taps, but the schedule and the
+    // immediate-offset reads carry over -- tools/probes/ab_wgrad_bias.py 64, with bias, single-tap kernel -> this: 1536->6144 @16
+    // 0.368 -> 0.305 ms, 6144->1536 0.290 -> 0.262, 1536->4608 0.265 -> 0.218, 768->3072 @32 0.345 -> 0.313, 3072->768 0.328 ->
+    // 0.294, 384->1536 @64 0.394 -> 0.320, 1536->384 0.354 -> 0.314 (809-1181 TFLOP/s; 45.5 -> 39.7 ms per micro-batch).
+    // 256 x 128 / 128 x 256 tiles measured 0-60 % slower than 192 x 192, schedule 0 2 % slower than schedule 4.
+    if (d->kh == 1 && d->kw == 1) {
+        const long long Ml = (long long)d->batch * d->h_out * d->w_out;
+        const bool ok = g_kx3_enable % 10 >= 2 && d->stride == 1 && d->pad == 0 && d->up_shift == 0 && d->dil_mask == 0 && d->h_in == d->h_out &&
+                        d->w_in == d->w_out && Ml % 64 == 0 && Ml * d->ldx * 2 < (1ll << 31) && Ml * d->ldo * 2 < (1ll << 31) &&
+                        d->c_out % 192 == 0 && d->c_in % 192 == 0;
+        if (!ok) return -1;
+        Kx3Args a;
+        a.x = (const bf16*)x; a.gy = (const bf16*)gy; a.dw = dw; a.dbias = dbias;
+        a.M = (int)Ml; a.h = 1; a.w = 64; a.c_in = d->c_in; a.ldx = d->ldx; a.c_out = d->c_out; a.ldo = d->ldo;
+        a.tiles_ci = 1; a.chunk_px = 0; a.hw_shift = 6; a.w_shift = 6; a.plain = 0;
+        a.xcd_order = 0; a.base = 1; a.ny = 1; a.accum = accum;
+        a.x_bytes = (unsigned)(Ml * d->ldx * 2);
+        // A/B: tv_set_wgrad_kx3(2 + 10 t, ...): t = 1: 256 x 128 tiles, t = 2: 128 x 256 tiles where they divide the layer
+        const int tsel = g_kx3_enable / 10;
+        if (tsel == 1 && d->c_out % 256 == 0 && d->c_in % 128 == 0) return kx3_launch_r<256, 128, 4, 2, 3, 64, 1>(a, s, plan_only);
+        if (tsel == 2 && d->c_out % 128 == 0 && d->c_in % 256 == 0) return kx3_launch_r<128, 256, 2, 4, 3, 64, 1>(a, s, plan_only);
+        return kx3_launch_r<192, 192, 4, 2, 3, 64, 1>(a, s, plan_only);
+    }
     const int wsh = log2_exact(d->w_out), hwsh = log2_exact(d->h_out * d->w_out);
     const long long M = (long long)d->batch * d->h_out * d->w_out;
     const long long xbytes = M * d->ldx * 2, gbytes = M * d->ldo * 2;

@@ -147,7 +147,7 @@ def load():
         lib.tv_set_wgrad_config.argtypes = [_I, _I, _I]
         lib.tv_set_wgrad_kx3.restype = _I
         lib.tv_set_wgrad_kx3.argtypes = [_I, _I, _I]
-        if os.environ.get("TV_WGRAD_KX3") is not None:     # A/B hook: 0 = 3x3 weight gradients through the single-tap kernel
+        if os.environ.get("TV_WGRAD_KX3") is not None:     # A/B hook: 0 = every weight gradient through the single-tap kernel, 1 = kx3 for 3x3 only
             lib.tv_set_wgrad_kx3(int(os.environ["TV_WGRAD_KX3"]), 0, 0)
         _lib = lib
     return _lib

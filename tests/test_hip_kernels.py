@@ -225,13 +225,40 @@ def test_wgrad_kx_triple(case):
                 ops.wgrad_acc(geo.fwd_desc(0), xd, gd, dw2, db2)
             torch.cuda.synchronize()
         finally:
-            lib.tv_set_wgrad_kx3(1, 0, 0)
+            lib.tv_set_wgrad_kx3(2, 0, 0)
         outs.append((dw.cpu(), db.cpu()))
         assert rel(dw, ref_dw) < 1e-2, ("single-tap" if single else "triple", rel(dw, ref_dw))
         assert rel(db, bn.grad) < 1e-2
     assert rel(outs[0][0], outs[1][0]) < 1e-4       # same bf16 products, fp32 sums in a different order
     assert rel(outs[0][1], outs[1][1]) < 1e-4
     assert rel(dw2 - 0.5, outs[0][0]) < 1e-4 and rel(db2 + 0.25, outs[0][1]) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(1024, 192, 384), (4096, 384, 192), (640, 768, 192)], ids=lambda s: "x".join(map(str, s)))
+def test_wgrad_linear_one_tap_instantiation(shape):
+    """The one-tap instantiation of the kx3 loop on linear layers (tv_set_wgrad_kx3(2, 0, 0); channels multiples of 192,
+    tokens a multiple of 64) against fp32 PyTorch and against the single-tap kernel."""
+    from transvae.hip import ops, _lib
+    T, Ci, Co = shape
+    g = torch.Generator().manual_seed(T + Ci)
+    x = r16(torch.randn(T, Ci, generator=g))
+    gy = r16(torch.randn(T, Co, generator=g))
+    ref_dw = gy.t() @ x
+    ref_db = gy.sum(0)
+    xd, gd, wd = x.to(dev(), BF), gy.to(dev(), BF), torch.zeros(Co, Ci, device=dev())
+    geo = ops._Geo("linear", xd, wd)
+    lib = _lib.load()
+    outs = []
+    for mode in (2, 1):
+        lib.tv_set_wgrad_kx3(mode, 0, 0)
+        try:
+            dw, db = ops.conv_wgrad(geo, wd, xd, gd, True)
+            torch.cuda.synchronize()
+        finally:
+            lib.tv_set_wgrad_kx3(2, 0, 0)
+        assert rel(dw, ref_dw) < 1e-2 and rel(db, ref_db) < 1e-2, (mode, rel(dw, ref_dw), rel(db, ref_db))
+        outs.append((dw.cpu(), db.cpu()))
+    assert rel(outs[0][0], outs[1][0]) < 1e-4 and rel(outs[0][1], outs[1][1]) < 1e-4
 
 
 DERIV_CASES = [

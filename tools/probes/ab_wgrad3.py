@@ -46,7 +46,7 @@ for (hw, Cc) in [(256, 192), (128, 192), (64, 384), (32, 768), (16, 1536)]:
                 else:
                     e = float((dw - ref[0]).norm() / ref[0].norm()), (float((db - ref[1]).norm() / ref[1].norm()) if BIAS else 0.0)
                     assert e[0] < 1e-4 and e[1] < 1e-4, (name, e)
-    lib.tv_set_wgrad_kx3(1, 0, 0)
+    lib.tv_set_wgrad_kx3(2, 0, 0)
     for name, ts in res.items():
         t = min(ts)
         print(f"wgrad{' +bias' if BIAS else '      '} c3s1 {Cc:4d}@{hw:<4d} mb{mb} {name:12s} min {t:7.3f} ms {f / t / 1e9:6.0f} TF/s   median {sorted(ts)[len(ts) // 2]:7.3f}", flush=True)

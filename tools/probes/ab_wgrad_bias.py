@@ -20,6 +20,10 @@ def tm(fn, it=10):
 
 
 print("library:", L.SO_PATH)
+if os.environ.get("AB_KX3_LINEAR"):     # linear layers through the one-tap instantiation of the kx3 loop: "enable[,ring]"
+    v = [int(t) for t in os.environ["AB_KX3_LINEAR"].split(",")]
+    L.load().tv_set_wgrad_kx3(v[0], v[1] if len(v) > 1 else 0, 0)
+    print("linear layers: one-tap kx3 instantiation", v)
 g = torch.Generator(device=dev).manual_seed(0)
 tot = {True: 0.0, False: 0.0}
 for (hw, Cin, Cout, n) in [(16, 1536, 6144, 24), (16, 6144, 1536, 24), (16, 1536, 4608, 12), (16, 1536, 1536, 12), (32, 768, 3072, 16), (32, 3072, 768, 16),
