@@ -303,18 +303,21 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_apply_kernel(const bf1
 
 // ---- token-row norms -------------------------------------------------------------------------
 constexpr int RN_MAXCH = 5;  // 16-byte chunks per lane: C <= 64*8*5 = 2560
+// KCH = chunks per lane the row actually needs (1: C <= 512, 2: <= 1024, 3: <= 1536, 5: <= 2560).  Round 3: the loops used to run
+// over all RN_MAXCH chunks whatever C was -- five times the arithmetic on a 384-channel row (stage 2 holds half of the row-norm
+// bytes), which made these HBM-rate kernels ALU-bound: rownorm_bwd<1> moved 0.8 GB in 0.50 ms on the 384-channel rows.
 
-template <int MODE>
+template <int MODE, int KCH>
 __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ w, bf16* __restrict__ y,
                                                           int T, int C, float eps_rms, float eps_ln) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nch = C >> 3;
     const float inv_c = 1.0f / (float)C;
-    float wv[RN_MAXCH][8];
+    float wv[KCH][8];
     if constexpr (MODE == 1) {
 #pragma unroll
-        for (int k = 0; k < RN_MAXCH; ++k) {
+        for (int k = 0; k < KCH; ++k) {
             const int ch = lane + 64 * k;
 #pragma unroll
             for (int e = 0; e < 8; ++e) wv[k][e] = (ch < nch) ? w[ch * 8 + e] : 0.f;
@@ -322,10 +325,10 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const bf16* __restrict
     }
     for (int row = blockIdx.x * 4 + wave; row < T; row += gridDim.x * 4) {
         const bf16* xr = x + (size_t)row * C;
-        float v[RN_MAXCH][8];
+        float v[KCH][8];
         float ss = 0.f;
 #pragma unroll
-        for (int k = 0; k < RN_MAXCH; ++k) {
+        for (int k = 0; k < KCH; ++k) {
             const int ch = lane + 64 * k;
             bf16x8 t = {0, 0, 0, 0, 0, 0, 0, 0};
             if (ch < nch) t = *(const bf16x8*)(xr + ch * 8);
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const bf16* __restrict
         if constexpr (MODE == 1) {
             float su = 0.f;
 #pragma unroll
-            for (int k = 0; k < RN_MAXCH; ++k)
+            for (int k = 0; k < KCH; ++k)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     v[k][e] = v[k][e] * r * wv[k][e];
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const bf16* __restrict
             mu = tv_wave_sum(su) * inv_c;
             float sv = 0.f;
 #pragma unroll
-            for (int k = 0; k < RN_MAXCH; ++k) {
+            for (int k = 0; k < KCH; ++k) {
                 const int ch = lane + 64 * k;
                 if (ch < nch) {
 #pragma unroll
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const bf16* __restrict
         }
         bf16* yr = y + (size_t)row * C;
 #pragma unroll
-        for (int k = 0; k < RN_MAXCH; ++k) {
+        for (int k = 0; k < KCH; ++k) {
             const int ch = lane + 64 * k;
             if (ch < nch) {
                 bf16x8 o;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(256) void rownorm_fwd_kernel(const bf16* __restrict
     }
 }
 
-template <int MODE>
+template <int MODE, int KCH>
 __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const bf16* __restrict__ x, const float* __restrict__ w, const bf16* __restrict__ dy,
                                                           const bf16* __restrict__ dres, bf16* __restrict__ dx, float* __restrict__ dw, int T,
                                                           int C, float eps_rms, float eps_ln) {
@@ -386,11 +389,11 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const bf16* __restrict
     const int wave = threadIdx.x >> 6;
     const int nch = C >> 3;
     const float inv_c = 1.0f / (float)C;
-    float wv[RN_MAXCH][8], dwv[RN_MAXCH][8];
+    float wv[KCH][8], dwv[KCH][8];
     if constexpr (MODE == 1) {
         for (int i = threadIdx.x; i < C; i += 256) s_dw[i] = 0.f;
 #pragma unroll
-        for (int k = 0; k < RN_MAXCH; ++k) {
+        for (int k = 0; k < KCH; ++k) {
             const int ch = lane + 64 * k;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -403,10 +406,10 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const bf16* __restrict
     for (int row = blockIdx.x * 4 + wave; row < T; row += gridDim.x * 4) {
         const bf16* xr = x + (size_t)row * C;
         const bf16* gr = dy + (size_t)row * C;
-        float xh[RN_MAXCH][8], g[RN_MAXCH][8];
+        float xh[KCH][8], g[KCH][8];
         float ss = 0.f;
 #pragma unroll
-        for (int k = 0; k < RN_MAXCH; ++k) {
+        for (int k = 0; k < KCH; ++k) {
             const int ch = lane + 64 * k;
             bf16x8 t = {0, 0, 0, 0, 0, 0, 0, 0}, u = {0, 0, 0, 0, 0, 0, 0, 0};
             if (ch < nch) {
@@ -423,20 +426,20 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const bf16* __restrict
         ss = tv_wave_sum(ss);
         const float r = rsqrtf(ss * inv_c + eps_rms);
 #pragma unroll
-        for (int k = 0; k < RN_MAXCH; ++k)
+        for (int k = 0; k < KCH; ++k)
 #pragma unroll
             for (int e = 0; e < 8; ++e) xh[k][e] *= r;  // xhat = x * r
         if constexpr (MODE == 1) {
             // u = xhat*w ; y = (u-mu)*s ; du = s*(dy - mean(dy) - y*mean(dy*y))
             float su = 0.f;
 #pragma unroll
-            for (int k = 0; k < RN_MAXCH; ++k)
+            for (int k = 0; k < KCH; ++k)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) su += xh[k][e] * wv[k][e];
             const float mu = tv_wave_sum(su) * inv_c;
             float sv = 0.f;
 #pragma unroll
-            for (int k = 0; k < RN_MAXCH; ++k) {
+            for (int k = 0; k < KCH; ++k) {
                 const int ch = lane + 64 * k;
                 if (ch < nch) {
 #pragma unroll
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const bf16* __restrict
             const float s = rsqrtf(tv_wave_sum(sv) * inv_c + eps_ln);
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < RN_MAXCH; ++k) {
+            for (int k = 0; k < KCH; ++k) {
                 const int ch = lane + 64 * k;
                 if (ch < nch) {
 #pragma unroll
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const bf16* __restrict
             a1 = tv_wave_sum(a1) * inv_c;
             a2 = tv_wave_sum(a2) * inv_c;
 #pragma unroll
-            for (int k = 0; k < RN_MAXCH; ++k) {
+            for (int k = 0; k < KCH; ++k) {
                 const int ch = lane + 64 * k;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -477,13 +480,13 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const bf16* __restrict
         // dx = r * (g - xhat * mean(g*xhat))
         float a3 = 0.f;
 #pragma unroll
-        for (int k = 0; k < RN_MAXCH; ++k)
+        for (int k = 0; k < KCH; ++k)
 #pragma unroll
             for (int e = 0; e < 8; ++e) a3 = fmaf(g[k][e], xh[k][e], a3);
         a3 = tv_wave_sum(a3) * inv_c;
         bf16* dr = dx + (size_t)row * C;
 #pragma unroll
-        for (int k = 0; k < RN_MAXCH; ++k) {
+        for (int k = 0; k < KCH; ++k) {
             const int ch = lane + 64 * k;
             if (ch < nch) {
                 bf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const bf16* __restrict
     }
     if constexpr (MODE == 1) {
 #pragma unroll
-        for (int k = 0; k < RN_MAXCH; ++k) {
+        for (int k = 0; k < KCH; ++k) {
             const int ch = lane + 64 * k;
             if (ch < nch) {
 #pragma unroll
@@ -590,10 +593,14 @@ extern "C" int tv_rownorm_fwd(const void* x, const float* w, void* y, int T, int
     TV_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 64 * 8 * RN_MAXCH, "tv_rownorm_fwd: C=%d must be a multiple of 8 and <= 2560", C);
     TV_CHECK_ARG(mode == 0 || (mode == 1 && w), "tv_rownorm_fwd: mode %d (mode 1 needs w)", mode);
     const int grid = min(tv_cdiv(T, 4), 256 * 8);
-    if (mode == 0)
-        hipLaunchKernelGGL(rownorm_fwd_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, w, (bf16*)y, T, C, eps_rms, eps_ln);
-    else
-        hipLaunchKernelGGL(rownorm_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, w, (bf16*)y, T, C, eps_rms, eps_ln);
+    const int kch = tv_cdiv(C >> 3, 64);      // 16-byte chunks per lane
+#define TV_RN_FWD(M, K) hipLaunchKernelGGL((rownorm_fwd_kernel<M, K>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, w, (bf16*)y, T, C, eps_rms, eps_ln)
+    if (mode == 0) {
+        if (kch <= 1) TV_RN_FWD(0, 1); else if (kch == 2) TV_RN_FWD(0, 2); else if (kch == 3) TV_RN_FWD(0, 3); else TV_RN_FWD(0, 5);
+    } else {
+        if (kch <= 1) TV_RN_FWD(1, 1); else if (kch == 2) TV_RN_FWD(1, 2); else if (kch == 3) TV_RN_FWD(1, 3); else TV_RN_FWD(1, 5);
+    }
+#undef TV_RN_FWD
     TV_CHECK_LAUNCH("tv_rownorm_fwd");
     return TV_OK;
 }
@@ -604,12 +611,15 @@ extern "C" int tv_rownorm_bwd(const void* x, const float* w, const void* dy, con
     TV_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 64 * 8 * RN_MAXCH, "tv_rownorm_bwd: C=%d must be a multiple of 8 and <= 2560", C);
     TV_CHECK_ARG(mode == 0 || (mode == 1 && w && dw), "tv_rownorm_bwd: mode %d (mode 1 needs w and dw)", mode);
     const int grid = min(tv_cdiv(T, 4), 256 * 4);
-    if (mode == 0)
-        hipLaunchKernelGGL(rownorm_bwd_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, w, (const bf16*)dy,
-                           (const bf16*)dres, (bf16*)dx, dw, T, C, eps_rms, eps_ln);
-    else
-        hipLaunchKernelGGL(rownorm_bwd_kernel<1>, dim3(grid), dim3(256), C * sizeof(float), (hipStream_t)stream, (const bf16*)x, w,
-                           (const bf16*)dy, (const bf16*)dres, (bf16*)dx, dw, T, C, eps_rms, eps_ln);
+    const int kch = tv_cdiv(C >> 3, 64);      // 16-byte chunks per lane
+#define TV_RN_BWD(M, K) hipLaunchKernelGGL((rownorm_bwd_kernel<M, K>), dim3(grid), dim3(256), (M) ? C * sizeof(float) : 0, (hipStream_t)stream, \
+                                           (const bf16*)x, w, (const bf16*)dy, (const bf16*)dres, (bf16*)dx, dw, T, C, eps_rms, eps_ln)
+    if (mode == 0) {
+        if (kch <= 1) TV_RN_BWD(0, 1); else if (kch == 2) TV_RN_BWD(0, 2); else if (kch == 3) TV_RN_BWD(0, 3); else TV_RN_BWD(0, 5);
+    } else {
+        if (kch <= 1) TV_RN_BWD(1, 1); else if (kch == 2) TV_RN_BWD(1, 2); else if (kch == 3) TV_RN_BWD(1, 3); else TV_RN_BWD(1, 5);
+    }
+#undef TV_RN_BWD
     TV_CHECK_LAUNCH("tv_rownorm_bwd");
     return TV_OK;
 }
