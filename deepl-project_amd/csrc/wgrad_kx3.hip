@@ -1,4 +1,5 @@
-// Weight gradient of 3x3 / stride-1 / pad-1 convolutions on image rows of >= 64 pixels ("kx-triple", round 3):
+// Weight gradient of 3x3 / stride-1 / pad-1 convolutions on image rows of >= 16 pixels ("kx-triple", round 3), and -- as the
+// one-tap instantiation of the same loop (TAPS = 1) -- of the linear / 1x1 layers:
 //
 //     dw[co][ky][kx][ci] += sum_p gy[p][co] * x[p + (ky-1) w + (kx-1)][ci]          dbias[co] += sum_p gy[p][co]
 //
@@ -17,7 +18,7 @@
 // reads the fragments of K-step t and issues its LDS-DMA pieces while group 1 multiplies step t - 1, then they swap: one
 // block barrier per phase.  LDS: a ring of RING stages (gy slots first, x slots after), K-step t + RING - 1 is issued during
 // step t.  Every fragment read is `base register + immediate`: the ring slot, the 32-pixel half of the step and the
-// 4-pixel half of the fragment are compile-time offsets (the step loop is unrolled RING times), so the load phase has no
+// 16-pixel half of the fragment are compile-time offsets (the step loop is unrolled RING times), so the load phase has no
 // address arithmetic.
 //
 // x image of a K-step (64 output pixels = 64 / SEG pieces of image rows, SEG = min(image width, 64) in {16, 32, 64}): each
