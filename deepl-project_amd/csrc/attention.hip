@@ -18,11 +18,31 @@
 #include "common.h"
 
 #include <type_traits>
+#include <utility>
 
 namespace {
 
+// Diagnostic builds only (tools/probes/build_variant.sh ... -DTV_ATTN_ABL=<mask>; results are wrong, times are what is read):
+// 1 no exponentials, 2 no second-phase MFMAs (P V / dS K / dV, dK), 4 no first-phase MFMAs (S, dP), 8 no DMA after the
+// prologue, 16 no barrier and no DMA wait, 32 no LDS fragment reads.
+#ifndef TV_ATTN_ABL
+#define TV_ATTN_ABL 0
+#endif
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+#if TV_ATTN_ABL & 4
+    c[0] += (float)a[0] * (float)b[0];
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x16 mfma32b(bf16x8 a, bf16x8 b, f32x16 c) {   // second phase of a tile
+#if TV_ATTN_ABL & 2
+    c[0] += (float)a[0] * (float)b[0];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 // ds_read_b64_tr_b16 via inline asm: the builtin makes hipcc (ROCm 7.2) drain vmcnt(0) before each transposed read
 // while an LDS-DMA is in flight, serialising the K/V DMA with compute.  Callers wait with lds_wait_all() before use.
@@ -36,7 +56,83 @@ __device__ __forceinline__ void lds_wait_all() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+#if TV_ATTN_ABL & 1
+__device__ __forceinline__ float fexp2(float x) { return x; }
+#else
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
+
+// ---- ring of K / V (Q / dO) stages -------------------------------------------------------------------------------
+// Round 3: the loops staged tile t+1 while computing tile t and opened every tile with `vmcnt(0)` + barrier: one tile of
+// matrix work (512 - 1024 cycles per wave) is about the latency of an LDS-DMA piece under load, and 0.24-0.28 of the
+// wave-cycles were parked (profiles/r03_attention_pmc.json).  The ring now holds NS stages, the DMA runs NS-1 tiles ahead and
+// a tile opens with a COUNTED wait: stage t must have landed, the NS-2 younger stages (PIECES DMA instructions each, per
+// wave, in issue order) may still be in flight.  Near the end of the sequence fewer stages are in flight: wait for all.
+// The barrier is the bare s_barrier (`__syncthreads()` adds a fence, for which hipcc drains vmcnt(0)).
+#ifndef TV_ATTN_NS
+#define TV_ATTN_NS 3        // forward, dq: stages of K 8 KiB + V 8 KiB (3 blocks of 48 KiB per CU)
+#endif
+#ifndef TV_ATTN_NS_DKV
+#define TV_ATTN_NS_DKV 3    // dk / dv: stages of Q 4 KiB + dO 4 KiB + 256 B
+#endif
+#ifndef TV_ATTN_SUM_MFMA
+#define TV_ATTN_SUM_MFMA 0  // forward: softmax row sums on the matrix pipe (an all-ones A operand) instead of 32 v_add_f32 per key block: measured 2.7 % SLOWER, off
+#endif
+#ifndef TV_ATTN_LAZY
+#define TV_ATTN_LAZY 8      // forward: rescale the running sums only when some row's maximum grew by more than this (log2 units); 0 = always
+#endif
+#ifndef TV_ATTN_DMA_LATE
+#define TV_ATTN_DMA_LATE 1    // next stage's DMA pieces after the first-phase MFMAs of a tile instead of right behind the barrier
+#endif
+#ifndef TV_ATTN_V_LATE
+#define TV_ATTN_V_LATE 0
+#endif
+#ifndef TV_ATTN_DELTA_MFMA
+#define TV_ATTN_DELTA_MFMA 1  // dq: -delta enters dP through one extra k-step (three bf16 pieces = fp32), not 16 v_add_f32 per tile
+#endif
+#ifndef TV_ATTN_DKV_ACCINIT
+#define TV_ATTN_DKV_ACCINIT 1 // dk / dv: -delta read from LDS straight into dP's initial accumulator
+#endif
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+#if !(TV_ATTN_ABL & 16)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+__device__ __forceinline__ void block_sync() {
+    __builtin_amdgcn_sched_barrier(0);
+#if !(TV_ATTN_ABL & 16)
+    __builtin_amdgcn_s_barrier();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int I>
+using ic = std::integral_constant<int, I>;
+// f(t, ic<t % NS>) for t = 0 .. n-1: the ring stage is a compile-time constant inside f (immediate LDS offsets)
+template <int NS, class F>
+__device__ __forceinline__ void ring_for(int n, F&& f) {
+    static_assert(NS >= 2 && NS <= 4, "ring of 2 to 4 stages");
+    for (int t = 0; t < n; t += NS) {
+        f(t, ic<0>{});
+        if (t + 1 < n) f(t + 1, ic<1>{});
+        if constexpr (NS > 2) {
+            if (t + 2 < n) f(t + 2, ic<2 % NS>{});
+        }
+        if constexpr (NS > 3) {
+            if (t + 3 < n) f(t + 3, ic<3 % NS>{});
+        }
+    }
+}
+// max over the two lane halves (lane i <-> lane i + 32) without LDS: v_permlane32_swap exchanges the upper half of its first
+// operand with the lower half of its second (the ds_bpermute of __shfl_xor cost an LDS round trip per key block)
+__device__ __forceinline__ float xhalf_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // LDS tiles are [rows][64] bf16 (128-byte rows, 8 chunks of 16 bytes); physical chunk = c ^ swz(row)
 __device__ __forceinline__ int swz_row(int r) { return (r >> 1) & 7; }          // conflict-free ds_read_b128 rows
@@ -137,6 +233,20 @@ __device__ __forceinline__ bf16x4 lds_tr16_imm(unsigned a) {
 // stage base joins the immediate and a fragment read is `base register + offset field`, nothing else: the forward loop
 // spent 41 of its ~230 vector-ALU issue slots per 64-key block on v_add_u32 of the stage base (the loops are bound by
 // their vector ALU work: profiles/r02_attention.json).  abs_* = LDS byte address of (tile 0 of stage 0) + the lane's part.
+#if TV_ATTN_ABL & 32
+template <int IMM>
+__device__ __forceinline__ bf16x8 read_rows_imm(const char* abs_row) {
+    bf16x8 r;
+    asm volatile("" : "=v"(r) : "v"(abs_row));
+    return r;
+}
+template <int IMM>
+__device__ __forceinline__ bf16x8 read_cols_imm(unsigned abs_lo, unsigned abs_hi) {
+    bf16x8 r;
+    asm volatile("" : "=v"(r) : "v"(abs_lo), "v"(abs_hi));
+    return r;
+}
+#else
 template <int IMM>
 __device__ __forceinline__ bf16x8 read_rows_imm(const char* abs_row) {
     return *(const bf16x8*)(abs_row + IMM);
@@ -147,6 +257,7 @@ __device__ __forceinline__ bf16x8 read_cols_imm(unsigned abs_lo, unsigned abs_hi
     const bf16x4 hi = lds_tr16_imm<IMM>(abs_hi);
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+#endif
 template <int R0>
 __device__ __forceinline__ bf16x8 read_cols_at(const char* tile, int off, int offh) {
     const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)tile;
@@ -209,7 +320,7 @@ __device__ __forceinline__ bool attn_block(const AttnArgs& p, int& tile, int& he
 // forward: block = 4 waves x 32 queries; loops over 64-key blocks (K: row tile, V: tr tile)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K 8 KiB + V 8 KiB)
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // TV_ATTN_NS stages x (K 8 KiB + V 8 KiB)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tile_x, head, b;
@@ -255,19 +366,37 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     stage_offsets<false>(vo_k, (int)ld, wave, lane);
     stage_offsets<true>(vo_v, (int)ld, wave, lane);
     const unsigned kv_bytes = stage_extent(p.N, (int)ld);
-    stage_rows_buf(smem, kbase, kv_bytes, 0, (int)ld, vo_k, wave);
-    stage_rows_buf(smem + KV_TILE, vbase, kv_bytes, 0, (int)ld, vo_v, wave);
+    constexpr int NS = TV_ATTN_NS, D = NS - 1;     // ring stages, DMA distance (tiles ahead)
+    constexpr int PIECES = 4;                      // LDS-DMA instructions per wave and stage (K 2 + V 2)
+    auto stage = [&](int t, char* sb) {
+        stage_rows_buf(sb, kbase, kv_bytes, t * 64, (int)ld, vo_k, wave);
+        stage_rows_buf(sb + KV_TILE, vbase, kv_bytes, t * 64, (int)ld, vo_v, wave);
+    };
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+        if (i < nblk) stage(i, smem + i * 2 * KV_TILE);
+#if TV_ATTN_SUM_MFMA
+    // row sums of P on the matrix pipe: an A operand of ones makes every row of  ones x P^T  the column sums of P^T, i.e.
+    // each lane receives sum_k P[q][k] over ALL 16 k slots (both lane halves) in every register of `lt` (only lt[0] is
+    // used).  4 more MFMAs per 64-key block against 32 v_add_f32 + a cross-half exchange: the loop is bound by its vector
+    // ALU work (~920 issue cycles per block beside 512 cycles of MFMA), the matrix pipe has the room.  The sum is taken over
+    // the bf16-rounded P that V is multiplied with (a normaliser consistent with the numerator).
+    const bf16 one_b = (bf16)1.0f;
+    const bf16x8 ones = {one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b};
+    f32x16 lt;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lt[i] = 0.f;
+#endif
     // one 64-key block out of ring stage S (compile-time)
     auto key_block = [&](int t, auto stage_c) {
         constexpr int S = decltype(stage_c)::value;
         constexpr int KB = S * 2 * KV_TILE, VB = KB + KV_TILE;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nblk) {
-            char* nb = smem + (1 - S) * 2 * KV_TILE;
-            stage_rows_buf(nb, kbase, kv_bytes, (t + 1) * 64, (int)ld, vo_k, wave);
-            stage_rows_buf(nb + KV_TILE, vbase, kv_bytes, (t + 1) * 64, (int)ld, vo_v, wave);
-        }
+        if (t + D - 1 < nblk) vm_wait<PIECES * (D - 1)>();
+        else vm_wait<0>();
+        block_sync();
+#if !TV_ATTN_DMA_LATE
+        if (!(TV_ATTN_ABL & 8) && t + D < nblk) stage(t + D, smem + ((S + D) % NS) * 2 * KV_TILE);
+#endif
         f32x16 s[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[0][i] = s[1][i] = 0.f;
@@ -279,15 +408,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         s[1] = mfma32(read_rows_imm<KB + 32 * 128>(abs_k[1]), qf[1], s[1]);
         s[1] = mfma32(read_rows_imm<KB + 32 * 128>(abs_k[2]), qf[2], s[1]);
         s[1] = mfma32(read_rows_imm<KB + 32 * 128>(abs_k[3]), qf[3], s[1]);
-        // V^T fragments of the whole 64-key block (transposed reads, asm): issued now, consumed after the softmax
+#if TV_ATTN_DMA_LATE
+        // the next stage's DMA pieces issue in the shadow of the eight S MFMAs (an LDS-DMA instruction holds its wave for
+        // 60-180 cycles; right after the barrier all four waves paid that with the matrix pipe idle)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(TV_ATTN_ABL & 8) && t + D < nblk) stage(t + D, smem + ((S + D) % NS) * 2 * KV_TILE);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         bf16x8 vfr[2][2][2];
+        auto read_v = [&]() {
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            vfr[0][0][db] = read_cols_imm<VB + 0 * 128>(abs_v[db], abs_vh[db]);
-            vfr[0][1][db] = read_cols_imm<VB + 16 * 128>(abs_v[db], abs_vh[db]);
-            vfr[1][0][db] = read_cols_imm<VB + 32 * 128>(abs_v[db], abs_vh[db]);
-            vfr[1][1][db] = read_cols_imm<VB + 48 * 128>(abs_v[db], abs_vh[db]);
-        }
+            for (int db = 0; db < 2; ++db) {
+                vfr[0][0][db] = read_cols_imm<VB + 0 * 128>(abs_v[db], abs_vh[db]);
+                vfr[0][1][db] = read_cols_imm<VB + 16 * 128>(abs_v[db], abs_vh[db]);
+                vfr[1][0][db] = read_cols_imm<VB + 32 * 128>(abs_v[db], abs_vh[db]);
+                vfr[1][1][db] = read_cols_imm<VB + 48 * 128>(abs_v[db], abs_vh[db]);
+            }
+        };
+#if !TV_ATTN_V_LATE
+        // V^T fragments of the whole 64-key block (transposed reads, asm): issued now, consumed after the softmax
+        read_v();
+#endif
         // online softmax over this lane's 32 keys (+ the other half-wave's 32); scores stay unscaled, the scale
         // rides in the exp2 FMA:  p = exp2(s*c2 - m*c2)
         const int kv0 = t * 64;
@@ -306,30 +447,74 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[kt][r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float mnew = fmaxf(m, mloc);
-        const float mc = mnew * c2;
-        float rs = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = fexp2(fmaf(s[kt][r], c2, -mc));
-                s[kt][r] = pv;
-                rs += pv;
-            }
-        rs += __shfl_xor(rs, 32, 64);
-        if (__any(mnew != m)) {   // some row's maximum moved: rescale the running sums (wave-uniform branch)
+        mloc = xhalf_max(mloc);
+        // Some row's maximum moved (TV_ATTN_LAZY = 0) / moved by more than 2^LAZY in the exponent: rescale the running sums
+        // (wave-uniform branch).  With LAZY > 0 a row may keep a maximum that is up to LAZY below its true one: p <= 2^LAZY,
+        // the same RELATIVE precision in bf16, sums in fp32; the statistic that leaves the kernel (lse) does not depend on it.
+#if TV_ATTN_LAZY > 0
+        const bool need = __any((mloc - m) * c2 > (float)TV_ATTN_LAZY);
+#else
+        const bool need = __any(mloc > m);
+#endif
+        if (need) {
+            const float mnew = fmaxf(m, mloc);
             const float alpha = fexp2((m - mnew) * c2);
+            m = mnew;
+#if TV_ATTN_SUM_MFMA
+            lt[0] *= alpha;
+#else
             l *= alpha;
+#endif
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 ot[0][i] *= alpha;
                 ot[1][i] *= alpha;
             }
         }
-        l += rs;
-        m = mnew;
+        const float mc = m * c2;
+#if !TV_ATTN_SUM_MFMA
+        float rs = 0.f;
+#endif
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fexp2(fmaf(s[kt][r], c2, -mc));
+                s[kt][r] = pv;
+#if !TV_ATTN_SUM_MFMA
+                rs += pv;
+#endif
+            }
+#if !TV_ATTN_SUM_MFMA
+        l += rs;           // this lane half's keys only: the halves are added once, after the loop
+#endif
+#if TV_ATTN_V_LATE == 1
+        __builtin_amdgcn_sched_barrier(0);
+        read_v();          // 32 registers less across the softmax
+#endif
+#if TV_ATTN_V_LATE == 2
+        // V^T fragments 32 keys at a time, right before their MFMAs: 16 live registers instead of 32 held across the softmax
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            bf16x8 vh[2][2];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                if (kt == 0) {
+                    vh[0][db] = read_cols_imm<VB + 0 * 128>(abs_v[db], abs_vh[db]);
+                    vh[1][db] = read_cols_imm<VB + 16 * 128>(abs_v[db], abs_vh[db]);
+                } else {
+                    vh[0][db] = read_cols_imm<VB + 32 * 128>(abs_v[db], abs_vh[db]);
+                    vh[1][db] = read_cols_imm<VB + 48 * 128>(abs_v[db], abs_vh[db]);
+                }
+            }
+            bf16x8 pf[2] = {pack_acc(s[kt], 0), pack_acc(s[kt], 1)};
+            lds_wait_all();
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) ot[db] = mfma32b(vh[ss][db], pf[ss], ot[db]);
+        }
+#else
         lds_wait_all();
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -337,13 +522,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             for (int ss = 0; ss < 2; ++ss) {
                 const bf16x8 pf = pack_acc(s[kt], ss);
 #pragma unroll
-                for (int db = 0; db < 2; ++db) ot[db] = mfma32(vfr[kt][ss][db], pf, ot[db]);
+                for (int db = 0; db < 2; ++db) ot[db] = mfma32b(vfr[kt][ss][db], pf, ot[db]);
+#if TV_ATTN_SUM_MFMA
+                lt = mfma32b(ones, pf, lt);
+#endif
             }
+#endif
     };
-    for (int t = 0; t < nblk; t += 2) {
-        key_block(t, std::integral_constant<int, 0>{});
-        if (t + 1 < nblk) key_block(t + 1, std::integral_constant<int, 1>{});
-    }
+    ring_for<NS>(nblk, key_block);
+#if TV_ATTN_SUM_MFMA
+    l = lt[0];
+#else
+    l = xhalf_sum(l);
+#endif
     if (q_ok) {
         const float inv = 1.0f / l;
         bf16* orow = p.out + ((size_t)b * p.N + qi) * C + head * 64;
@@ -451,8 +642,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     int vo_kv[2];
     stage_offsets<false>(vo_kv, (int)ld, wave, lane);
     const unsigned kv_bytes = stage_extent(p.N, (int)ld);
-    stage_rows_buf(smem, kbase, kv_bytes, 0, (int)ld, vo_kv, wave);
-    stage_rows_buf(smem + KV_TILE, vbase, kv_bytes, 0, (int)ld, vo_kv, wave);
+    constexpr int NS = TV_ATTN_NS, D = NS - 1;
+    constexpr int PIECES = 4;
+    auto stage = [&](int t, char* sb) {
+        stage_rows_buf(sb, kbase, kv_bytes, t * 64, (int)ld, vo_kv, wave);
+        stage_rows_buf(sb + KV_TILE, vbase, kv_bytes, t * 64, (int)ld, vo_kv, wave);
+    };
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+        if (i < nblk) stage(i, smem + i * 2 * KV_TILE);
+#if TV_ATTN_DELTA_MFMA
+    // dP - delta out of the MFMA chain: one more k-step whose A operand holds 1 in k slots 0..2 (every key row) and whose B
+    // operand holds -delta of the lane's query as three bf16 pieces (hi + mid + lo = the fp32 value to 2^-24) in the same
+    // slots.  The query is on the LANE here, so starting the accumulator from -delta would take 16 register broadcasts per
+    // tile -- as many vector instructions as the 16 v_add_f32 it removes; the extra MFMA takes none (the loop is bound by
+    // its vector ALU work, the matrix pipe is ~0.58 busy).
+    bf16x8 dl_a = {0, 0, 0, 0, 0, 0, 0, 0}, dl_b = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const bf16 d0 = (bf16)nd;
+        const float r1 = nd - (float)d0;
+        const bf16 d1 = (bf16)r1;
+        const bf16 d2 = (bf16)(r1 - (float)d1);
+        if (h == 0) {
+            const bf16 one_b = (bf16)1.0f;
+            dl_a[0] = dl_a[1] = dl_a[2] = one_b;
+            dl_b[0] = d0;
+            dl_b[1] = d1;
+            dl_b[2] = d2;
+        }
+    }
+#endif
     // 32 keys (half KT of a 64-key block) out of ring stage S, both compile-time
     auto half_block = [&](int t, auto stage_c, auto kt_c) {
         constexpr int S = decltype(stage_c)::value, KT = decltype(kt_c)::value;
@@ -460,6 +679,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         f32x16 s, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+#if TV_ATTN_DELTA_MFMA
+        dp = mfma32(dl_a, dl_b, dp);
+#endif
         s = mfma32(read_rows_imm<KB + RO>(abs_r[0]), qf[0], s);
         dp = mfma32(read_rows_imm<VB + RO>(abs_r[0]), gf[0], dp);
         s = mfma32(read_rows_imm<KB + RO>(abs_r[1]), qf[1], s);
@@ -468,6 +690,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         dp = mfma32(read_rows_imm<VB + RO>(abs_r[2]), gf[2], dp);
         s = mfma32(read_rows_imm<KB + RO>(abs_r[3]), qf[3], s);
         dp = mfma32(read_rows_imm<VB + RO>(abs_r[3]), gf[3], dp);
+#if TV_ATTN_DMA_LATE
+        if constexpr (KT == 0) {   // the next stage's DMA pieces in the shadow of the first S / dP MFMAs (see attn_fwd_kernel)
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(TV_ATTN_ABL & 8) && t + D < nblk) stage(t + D, smem + ((S + D) % NS) * 2 * KV_TILE);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
         bf16x8 kfr[2][2];   // K^T fragments (transposed asm reads): in flight during the exponentials
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
@@ -483,31 +712,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = fexp2(fmaf(s[r], c2, nl)) * (dp[r] + nd);  // dS^T (without the factor `scale`)
+        for (int r = 0; r < 16; ++r) {   // dS^T (without the factor `scale`)
+#if TV_ATTN_DELTA_MFMA
+            s[r] = fexp2(fmaf(s[r], c2, nl)) * dp[r];
+#else
+            s[r] = fexp2(fmaf(s[r], c2, nl)) * (dp[r] + nd);
+#endif
+        }
         lds_wait_all();
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const bf16x8 df = pack_acc(s, ss);
 #pragma unroll
-            for (int db = 0; db < 2; ++db) dqt[db] = mfma32(kfr[ss][db], df, dqt[db]);
+            for (int db = 0; db < 2; ++db) dqt[db] = mfma32b(kfr[ss][db], df, dqt[db]);
         }
     };
     auto key_block = [&](int t, auto stage_c) {
         constexpr int S = decltype(stage_c)::value;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nblk) {
-            char* nb = smem + (1 - S) * 2 * KV_TILE;
-            stage_rows_buf(nb, kbase, kv_bytes, (t + 1) * 64, (int)ld, vo_kv, wave);
-            stage_rows_buf(nb + KV_TILE, vbase, kv_bytes, (t + 1) * 64, (int)ld, vo_kv, wave);
-        }
-        half_block(t, stage_c, std::integral_constant<int, 0>{});
-        half_block(t, stage_c, std::integral_constant<int, 1>{});
+        if (t + D - 1 < nblk) vm_wait<PIECES * (D - 1)>();
+        else vm_wait<0>();
+        block_sync();
+#if !TV_ATTN_DMA_LATE
+        if (!(TV_ATTN_ABL & 8) && t + D < nblk) stage(t + D, smem + ((S + D) % NS) * 2 * KV_TILE);
+#endif
+        half_block(t, stage_c, ic<0>{});
+        half_block(t, stage_c, ic<1>{});
     };
-    for (int t = 0; t < nblk; t += 2) {
-        key_block(t, std::integral_constant<int, 0>{});
-        if (t + 1 < nblk) key_block(t + 1, std::integral_constant<int, 1>{});
-    }
+    ring_for<NS>(nblk, key_block);
     if (q_ok) {
         bf16* row = p.out + ((size_t)b * p.N + qi) * ld + head * 64;  // q third of dqkv
 #pragma unroll
@@ -593,18 +824,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         abs_ch[db] = smem_addr + off_ch[db];
     }
     const char* abs_st = smem + 2 * QT_TILE + 16 * h;      // this lane half's part of the lse / delta rows
-    stage(0, smem);
+    constexpr int NS = TV_ATTN_NS_DKV, D = NS - 1;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+        if (i < ntile) stage(i, smem + i * DKV_STAGE);
     // one 32-query tile out of ring stage S (compile-time)
     auto query_tile = [&](int t, auto stage_c) {
         constexpr int S = decltype(stage_c)::value;
         constexpr int QB = S * DKV_STAGE, GB = QB + QT_TILE;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < ntile) stage(t + 1, smem + (1 - S) * DKV_STAGE);
+        if (t + D - 1 < ntile) {       // per-wave DMA instructions of a stage: Q 1 + dO 1, wave 0 also the lse / delta row
+            if (wave == 0) vm_wait<3 * (D - 1)>();
+            else vm_wait<2 * (D - 1)>();
+        } else {
+            vm_wait<0>();
+        }
+        block_sync();
+#if !TV_ATTN_DMA_LATE
+        if (!(TV_ATTN_ABL & 8) && t + D < ntile) stage(t + D, smem + ((S + D) % NS) * DKV_STAGE);
+#endif
         f32x16 s, dp;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;   // (inline-constant accumulator start: see attn_bwd_dq_kernel)
-        f32x4 nl[4], nd[4];                                // accumulator rows (queries) 8g+4h+{0..3}
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;   // (inline-constant accumulator start: see attn_bwd_dq_kernel)
+        f32x4 nl[4], nd[4];                        // accumulator rows (queries) 8g+4h+{0..3}
         nl[0] = *(const f32x4*)(abs_st + QB + 0);
         nl[1] = *(const f32x4*)(abs_st + QB + 32);
         nl[2] = *(const f32x4*)(abs_st + QB + 64);
@@ -613,6 +854,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         nd[1] = *(const f32x4*)(abs_st + QB + 128 + 32);
         nd[2] = *(const f32x4*)(abs_st + QB + 128 + 64);
         nd[3] = *(const f32x4*)(abs_st + QB + 128 + 96);
+#if TV_ATTN_DKV_ACCINIT
+        // the query is on the accumulator ROW here: -delta of rows 8g+4h+{0..3} is one broadcast 16-byte LDS read per g and
+        // IS dP's initial accumulator as it arrives (no 16 v_add_f32 per tile, no second copy in registers)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = nd[r >> 2][r & 3];
+#else
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dp[i] = 0.f;
+#endif
         s = mfma32(read_rows_imm<QB>(abs_r[0]), kf[0], s);
         dp = mfma32(read_rows_imm<GB>(abs_r[0]), vf[0], dp);
         s = mfma32(read_rows_imm<QB>(abs_r[1]), kf[1], s);
@@ -621,6 +871,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         dp = mfma32(read_rows_imm<GB>(abs_r[2]), vf[2], dp);
         s = mfma32(read_rows_imm<QB>(abs_r[3]), kf[3], s);
         dp = mfma32(read_rows_imm<GB>(abs_r[3]), vf[3], dp);
+#if TV_ATTN_DMA_LATE
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(TV_ATTN_ABL & 8) && t + D < ntile) stage(t + D, smem + ((S + D) % NS) * DKV_STAGE);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         bf16x8 gfr[2][2], qfr[2][2];   // dO^T and Q^T fragments (transposed asm reads)
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
@@ -634,7 +889,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         for (int r = 0; r < 16; ++r) {
             const float pv = fexp2(fmaf(s[r], c2, nl[r >> 2][r & 3]));
             s[r] = pv;
+#if TV_ATTN_DKV_ACCINIT
+            dp[r] = pv * dp[r];
+#else
             dp[r] = pv * (dp[r] + nd[r >> 2][r & 3]);
+#endif
         }
         lds_wait_all();
 #pragma unroll
@@ -643,15 +902,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
             const bf16x8 df = pack_acc(dp, ss);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                dvt[db] = mfma32(gfr[ss][db], pf, dvt[db]);
-                dkt[db] = mfma32(qfr[ss][db], df, dkt[db]);
+                dvt[db] = mfma32b(gfr[ss][db], pf, dvt[db]);
+                dkt[db] = mfma32b(qfr[ss][db], df, dkt[db]);
             }
         }
     };
-    for (int t = 0; t < ntile; t += 2) {
-        query_tile(t, std::integral_constant<int, 0>{});
-        if (t + 1 < ntile) query_tile(t + 1, std::integral_constant<int, 1>{});
-    }
+    ring_for<NS>(ntile, query_tile);
     if (k_ok) {
         bf16* krow = p.out + ((size_t)b * p.N + ki) * ld + C + head * 64;
         bf16* vrow = krow + C;
@@ -679,6 +935,12 @@ int attn_check(const char* name, int B, int N, int heads, float scale) {
 
 }  // namespace
 
+static int g_attn_bwd_mask = 7;   // timing hook (tools/probes): 1 delta, 2 dq, 4 dk/dv; not part of the public ABI
+extern "C" int tv_set_attn_bwd_mask(int mask) {
+    g_attn_bwd_mask = mask;
+    return TV_OK;
+}
+
 extern "C" int tv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int heads, float scale, void* stream) {
     if (attn_check("tv_attn_fwd", B, N, heads, scale)) return TV_ERR_ARG;
     TV_CHECK_ARG(qkv && o && lse, "tv_attn_fwd: null pointer");
@@ -688,7 +950,7 @@ extern "C" int tv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, i
     a.qkv = (const bf16*)qkv; a.out = (bf16*)o; a.lse = lse; a.zeros = (const char*)tv_zero_page();
     a.B = B; a.N = N; a.heads = heads; a.scale = scale;
     dim3 grid((unsigned)(8 * tv_cdiv(N, 128) * tv_cdiv((long long)heads * B, 8)));
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * KV_TILE, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), TV_ATTN_NS * 2 * KV_TILE, (hipStream_t)stream, a);
     TV_CHECK_LAUNCH("tv_attn_fwd");
     return TV_OK;
 }
@@ -708,10 +970,10 @@ extern "C" int tv_attn_bwd(const void* qkv, const void* o, const void* d_o, cons
     const long long tot = (long long)B * N * heads * 8;
     long long g = (tot + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)g), dim3(256), 0, s, a);
+    if (g_attn_bwd_mask & 1) hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)g), dim3(256), 0, s, a);
     dim3 grid((unsigned)(8 * tv_cdiv(N, 128) * tv_cdiv((long long)heads * B, 8)));
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 4 * KV_TILE, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 2 * DKV_STAGE, s, a);
+    if (g_attn_bwd_mask & 2) hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), TV_ATTN_NS * 2 * KV_TILE, s, a);
+    if (g_attn_bwd_mask & 4) hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), TV_ATTN_NS_DKV * DKV_STAGE, s, a);
     TV_CHECK_LAUNCH("tv_attn_bwd");
     return TV_OK;
 }

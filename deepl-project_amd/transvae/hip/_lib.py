@@ -94,7 +94,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
     # attention post-processes its MFMA results with VALU work (softmax): keep them in VGPRs, or every block
     # pays ~160 v_accvgpr_read/write copies (measured: 29 VALU instructions per MFMA before, profiles/)
-    extra = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+    # -fno-slp-vectorize: the SLP pass packs the softmax's multiplies / adds into v_pk_*_f32 on MISALIGNED register pairs
+    # and pays for it with v_mov / v_perm / v_alignbit shuffles (dk/dv loop: 16 v_mul became 8 v_pk_mul + 14 moves), and
+    # packed fp32 is slower than two scalar operations next to MFMAs anyway (MI355X guide, cycle constants)
+    extra = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
     procs = []
     objs = []
     for s in srcs:

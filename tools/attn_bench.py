@@ -15,8 +15,8 @@ for (C, N, nblk) in ((384, 4096, 6), (768, 1024, 8), (1536, 256, 12)):
         return ops.attention(qkv, None, heads, 0.125)
     def fb():
         o = ops.attention(qkv, None, heads, 0.125); o.backward(go); qkv.grad = None
-    def tm(fn, it=5):
-        for _ in range(2): fn()
+    def tm(fn, it=20):
+        for _ in range(3): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(it): fn()

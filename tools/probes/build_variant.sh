@@ -5,7 +5,8 @@ set -e
 name=$1; src=$2; shift 2
 cd "$(dirname "$0")/../../deepl-project_amd"
 mkdir -p ../tools/probes/abl
-extra=""; [ "$src" = "attention.hip" ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
+extra=""; [ "$src" = "attention.hip" ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
+[ "$src" = "attention.hip" ] && [ -n "$TV_SLP" ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"   # TV_SLP=1: with the SLP vectorizer (A/B)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value $extra "$@" -c csrc/$src -o /tmp/var_${name}_${src%.hip}.o
 objs=""
 for f in csrc/*.hip; do
