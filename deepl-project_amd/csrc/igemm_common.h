@@ -27,6 +27,7 @@ struct IgemmArgs {
     int h_out, w_out, ldo;
     int kh, kw, stride, pad, up_shift, dil_mask;
     int tiles_n, tiles_m, xcd_order;
+    int tpb, nchunks;  // persistent column loop: a block walks `tpb` consecutive column tiles of its row tile (nchunks = tiles_n / tpb)
     int shuffle;
     int act;
     int aux_act;
@@ -91,6 +92,9 @@ using namespace tvi;
 #endif
 #ifndef TV_GENERIC_DPHASE
 #define TV_GENERIC_DPHASE 1   // generic pipelined loop: DMA slots staggered by wave through a run-time phase (scalar branches in the MFMA stream)
+#endif
+#ifndef TV_PERSIST_DRAIN
+#define TV_PERSIST_DRAIN 0    // persistent column loop: 1 = open every tile with vmcnt(0) (drains the previous tile's stores too), for A/B
 #endif
 #ifndef TV_NO_PINGPONG
 #define TV_NO_PINGPONG 1   // ping-pong main loop of the 8-wave tiles: measured, not (yet) a win -- see DESIGN.md

@@ -81,7 +81,38 @@ constexpr int igemm_min_waves() {
     return w >= 2 ? 2 : 1;
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE, int EPI>
+// Persistent tile walk (round 3).  A block of the plain two-stage DMA loop (the 256 x 256 tile) on a single-tap layer (1x1 /
+// linear) walks a LIST of output tiles as ONE K-loop: the staging state wraps from the last K-step of a tile to step 0 of the
+// block's next tile (both operands move through the scalar offset of their DMA pieces), so the first stage of the next tile
+// is issued before the last K-step of the current one and lands under that step and under the register epilogue, which uses
+// no LDS.  What this removes per tile: block dispatch, the offset set-up and -- the large part, 3.4 us of a 20-50 us tile --
+// the first DMA round trip, which every CU of a launch used to pay at the same moment (the chip-wide prologue burst runs at
+// ~11 B/clk/CU).  The wait that opens the next tile is COUNTED: vmcnt counts loads, stores and DMA together in issue order,
+// so behind the prefetched pieces sit the epilogue's stores -- exactly NST per wave on a full tile -- and `vmcnt(NST)` retires
+// the pieces without draining the stores (a persistent trial on the halo kernel in round 2 waited vmcnt(0) there: 1.00x).
+// Which tiles: the blocks with id = x mod 8 share an XCD (round-robin placement) and own the row tiles = x mod 8, listed row
+// tile by row tile (the column tiles of a row tile adjacent); block b of the P on that XCD takes list entries b, b + P, ...:
+// at any moment the XCD's blocks sit on neighbouring entries, i.e. the column tiles of ONE or two row tiles, and share those
+// activation rows through its L2 as the one-tile-per-block order did.  (A first form -- each block walking the column tiles
+// of its own row tile -- re-read that row tile from HBM once per column tile wherever the row tiles of an XCD's blocks exceed
+// its L2: K = 3072 -> N = 768 ran 0.269 -> 0.334 ms.)
+template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE>
+constexpr bool igemm_persist_ok() {
+    constexpr int MF = BM / WGM / 16, NF = BN / WGN / 16, NW = WGM * WGN;
+    constexpr bool pipe_all = (MF + NF) * 4 * (BK / 32) <= TV_PIPE_ALL_MAX;
+    constexpr bool pingpong = MODE != 0 && STAGES == 2 && NW == 8 && pipe_all && !TV_NO_PINGPONG;
+    constexpr bool pipe2 = MODE != 0 && pipe_all && BK == 64 && !pingpong && !TV_NO_PIPE2;
+    return MODE == 2 && STAGES == 2 && !pipe2 && !pingpong && BM * BN >= 128 * 128 && (NF % 2 == 0) && !TV_EPI_LDS && TV_GENERIC_BURST;
+}
+// store instructions per wave of a register epilogue form on a full tile (epilogue_direct: per fragment row two per pair of
+// 32-channel blocks + one for a block without a partner; twice that where the derivative is saved as well)
+template <int WTM, int WTN>
+__device__ __forceinline__ constexpr int epi_store_count(bool saves) {
+    constexpr int MF = WTM / 16, NC = WTN / 32;
+    return MF * (2 * (NC / 2) + (NC & 1)) * (saves ? 2 : 1);
+}
+
+template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE, int EPI, bool PERS = false, int PFORM = 0>
 __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, BK, STAGES>())) void igemm_nt_kernel(const IgemmArgs p) {
     constexpr bool DMA = MODE != 0, BUF = MODE == 2;
     constexpr int NW = WGM * WGN;
@@ -110,8 +141,22 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
     // its L2 instead of fetching them tiles_n times from HBM / Infinity Cache (a K = 384, N = 1536 linear layer moved
     // 2.4 GB in 0.47 ms that way: memory bound).  Workgroups go to XCDs round-robin by linear id, so row tile m takes
     // the ids congruent to m mod 8, its column tiles consecutive within that XCD's sequence.
+    // PERS instantiations serve single-tap layers only (1x1 / linear, stride 1: K = c_in): the gather state of the taps
+    // (pixel coordinates per staged row) is dead after the first offset set-up instead of living across every epilogue
+    constexpr bool PERSIST = PERS && igemm_persist_ok<BM, BN, WGM, WGN, BK, STAGES, MODE>();
     int tile_n, tile_m;
-    if (p.xcd_order) {
+    int ntile = 1;   // tiles this block walks
+    [[maybe_unused]] int walk_i = 0, walk_x = 0;   // persistent walk: entry of the XCD's tile list being COMPUTED, XCD label
+    if constexpr (PERSIST) {
+        walk_x = blockIdx.x & 7;
+        walk_i = blockIdx.x >> 3;
+        const int nlist = ((p.tiles_m - walk_x + 7) >> 3) * p.tiles_n;   // row tiles = walk_x mod 8, times the column tiles
+        if (walk_i >= nlist) return;
+        ntile = (nlist - 1 - walk_i) / p.nchunks + 1;                    // (p.nchunks = blocks per XCD label)
+        const int r = walk_i / p.tiles_n;
+        tile_n = walk_i - r * p.tiles_n;
+        tile_m = r * 8 + walk_x;
+    } else if (p.xcd_order) {
         const int lin = blockIdx.x, j = lin >> 3;
         tile_n = j % p.tiles_n;
         tile_m = (j / p.tiles_n) * 8 + (lin & 7);
@@ -120,7 +165,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
         tile_n = blockIdx.x % p.tiles_n;
         tile_m = blockIdx.x / p.tiles_n;
     }
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    int m0 = tile_m * BM;
+    int n0 = tile_n * BN;
 
     // ---- per-thread staging bookkeeping ------------------------------------------------
     const int srow = lane / CPR;   // row inside a DMA piece
@@ -179,6 +225,9 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
     const int nk = p.kh * p.kw * cch;
 #endif
     int st_ky = 0, st_kx = 0, st_ch = 0, st_t = 0;
+    // persistent walk: list entry being STAGED, byte offsets of its activation rows / weight rows (the per-lane offsets are
+    // tile-local there, see persist_reinit)
+    [[maybe_unused]] int st_i = walk_i, st_am = m0 * p.ldx * 2, st_nb = n0 * p.K * 2;
     const bf16* a_src[A_IT];
     bool a_ok[A_IT];
     int a_voff[A_IT];
@@ -215,7 +264,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
                 return;
             }
             if constexpr (BUF) {
-                buffer_load_lds16(p.x, p.x_bytes, sbase + j * 1024, a_voff[it], koff * 2);
+                buffer_load_lds16(p.x, p.x_bytes, sbase + j * 1024, a_voff[it], koff * 2 + (PERSIST ? st_am : 0));
             } else if constexpr (DMA) {
                 const void* src = a_ok[it] ? (const void*)(a_src[it] + koff) : (const void*)(p.zeros + lane * 16);
                 __builtin_amdgcn_global_load_lds(TV_GLB(src), TV_LDS(sbase + j * 1024), 16, 0, 0);
@@ -233,7 +282,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
                 return;
             }
             if constexpr (BUF) {
-                buffer_load_lds16(p.w, p.w_bytes, sbase + A_BYTES + j * 1024, b_voff[it], kb * 2);
+                buffer_load_lds16(p.w, p.w_bytes, sbase + A_BYTES + j * 1024, b_voff[it], kb * 2 + (PERSIST ? st_nb : 0));
             } else if constexpr (DMA) {
                 const void* src = b_ok[it] ? (const void*)(b_src[it] + kb) : (const void*)(p.zeros + lane * 16);
                 __builtin_amdgcn_global_load_lds(TV_GLB(src), TV_LDS(sbase + A_BYTES + j * 1024), 16, 0, 0);
@@ -245,6 +294,18 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
         }
     };
     auto stage_advance = [&]() {   // move the staging state to the following K-step
+        if constexpr (PERSIST) {   // single tap: the K-step is the channel chunk; behind the last one, step 0 of the next column tile
+            ++st_t;
+            ++st_ch;
+            if (st_t == nk) {   // on to the block's next list entry (behind its last tile nothing is issued any more)
+                st_i += p.nchunks;
+                const int r = st_i / p.tiles_n, c = st_i - r * p.tiles_n;
+                st_am = (r * 8 + walk_x) * (BM * p.ldx * 2);
+                st_nb = c * (BN * p.K * 2);
+                st_t = st_ch = 0;
+            }
+            return;
+        }
         ++st_t;
         if (++st_ch == cch) {
             st_ch = 0;
@@ -279,10 +340,34 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
     };
 
     // ---- fragment addressing -------------------------------------------------------------
-    const int fi = lane & 15, fq = lane >> 4;
-    const int sw = swz_of<BK>(fi);
-    const int a_row_off = (wm * WTM + fi) * (BK * 2);
-    const int b_row_off = A_BYTES + (wn * WTN + bfrag_lane_row(fi)) * (BK * 2);
+    int fi = lane & 15, fq = lane >> 4;
+    int sw = swz_of<BK>(fi);
+    int a_row_off = (wm * WTM + fi) * (BK * 2);
+    int b_row_off = A_BYTES + (wn * WTN + bfrag_lane_row(fi)) * (BK * 2);
+    // Persistent loop: the main loop's per-lane state (DMA offsets, fragment addresses: ~20 registers) is REBUILT behind every
+    // epilogue from a lane id the optimiser cannot see through, so that it does not live across the epilogue (nor the
+    // epilogue's own lane arithmetic across the main loop): with both alive at once the EPI 0 instantiation spilled, and a
+    // reload inside the K-loop waits vmcnt(0), i.e. for the DMA burst just issued.  Single tap: a staged row's pixel is m.
+    [[maybe_unused]] auto persist_reinit = [&]() {
+        int tl = threadIdx.x;
+        asm volatile("" : "+v"(tl));
+        const int ln = tl & 63, sr = ln / CPR, ss = ln % CPR;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {   // tile-local: the tile's first row / weight row rides in the scalar offset
+            const int row = (it * NW + wave) * RPI + sr;
+            a_voff[it] = (row * p.ldx + (ss ^ swz_of<BK>(row & 15)) * 8) * 2;
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int row = (it * NW + wave) * RPI + sr;
+            b_voff[it] = (row * p.K + (ss ^ swz_of<BK>(bfrag_reader(row % WTN))) * 8) * 2;
+        }
+        fi = ln & 15;
+        fq = ln >> 4;
+        sw = swz_of<BK>(fi);
+        a_row_off = (wm * WTM + fi) * (BK * 2);
+        b_row_off = A_BYTES + (wn * WTN + bfrag_lane_row(fi)) * (BK * 2);
+    };
 
     f32x4 acc[MF][NF];
 #pragma unroll
@@ -344,15 +429,26 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
             for (int kk = 0; kk < BK / 32; ++kk) {
                 const int coff = ((kk * 4 + fq) ^ sw) * 16;
                 bf16x8 af[MF], bfr[NF];
+#ifdef TV_ABL_NO_LDSREAD
+#pragma unroll
+                for (int i = 0; i < MF; ++i) { af[i] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(af[i])); }
+#pragma unroll
+                for (int j = 0; j < NF; ++j) { bfr[j] = bf16x8{1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(bfr[j])); }
+#else
 #pragma unroll
                 for (int i = 0; i < MF; ++i) af[i] = *(const bf16x8*)(sbase + a_row_off + i * 16 * (BK * 2) + coff);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) bfr[j] = *(const bf16x8*)(sbase + b_row_off + bfrag_off(j) * (BK * 2) + coff);
+#endif
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
                     for (int j = 0; j < NF; ++j) {
+#ifdef TV_ABL_NO_MFMA
+                        asm volatile("" ::"v"(bfr[j]), "v"(af[i]));
+#else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+#endif
                         const int idx = (kk * MF + i) * NF + j;
                         if (ISSUE && idx % GAP == GAP - 1 && idx / GAP < NI) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -486,6 +582,63 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
             if (grp == 0) wait_vmcnt<0>();
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
+    } else if constexpr (DMA && PERSIST) {
+        // one K-loop over the block's ntile column tiles (STAGES == 2, burst issue): step g stages step g + 1, whichever tile
+        // that belongs to; a tile's epilogue follows its last step
+        const int total = ntile * nk;
+        constexpr bool full_rows = true;   // (the host sends only M % BM == 0 here: every staged row and every store is in range)
+        persist_reinit();
+        stage_issue(smem);
+        int cur = 0, t = 0;
+        bool after_epi = false;
+        for (int g = 0; g < total; ++g) {
+            if (after_epi) {
+                // behind the prefetched pieces of this step: the previous tile's stores (NST per wave on a full tile; a ragged
+                // one may have skipped some: drain)
+                constexpr int NST = epi_store_count<WTM, WTN>(PFORM == EF_GELU_D || PFORM == EF_SILU_D);
+                static_assert(NST <= 63, "vmcnt field");
+                if (!full_rows || TV_PERSIST_DRAIN) wait_vmcnt<0>();
+                else wait_vmcnt<NST>();
+                after_epi = false;
+            } else {
+                wait_vmcnt<0>();
+            }
+            TV_T(0);
+            __builtin_amdgcn_s_barrier();
+            TV_T(1);
+            if (g + 1 < total) stage_issue(smem + (cur ^ 1) * STAGE);
+            compute(smem + cur * STAGE, nullptr, std::false_type{});
+            TV_T(4);
+            cur ^= 1;
+            if (++t == nk) {   // the tile is complete
+                t = 0;
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 bvals[NF];
+                int mrow0 = m0 + wm * WTM, elane = threadIdx.x;
+                asm volatile("" : "+s"(mrow0));   // per tile: the epilogue's row / offset / lane arithmetic must not be hoisted
+                asm volatile("" : "+v"(elane));   // out of the tile loop (it would live in ~60 registers across the main loop)
+                elane &= 63;
+                load_bias<WTN>(p, elane, n0 + wn * WTN, bvals);
+                // ONE register form per instantiation (PFORM): the run-time switch over all of them inside the tile loop cost the
+                // EPI 0 kernel 251 registers and 104 SGPRs (lane-spilled in the K-loop): 3-9 % SLOWER than one tile per block
+                epilogue_direct<WTM, WTN, PFORM>(p, acc, bvals, elane, n0 + wn * WTN, [&](int r) { return mrow0 + r; });
+                __builtin_amdgcn_sched_barrier(0);
+                persist_reinit();   // (unconditional: the old values are dead behind every epilogue, nothing to keep or spill)
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                walk_i += p.nchunks;
+                {
+                    const int r = walk_i / p.tiles_n;
+                    n0 = (walk_i - r * p.tiles_n) * BN;
+                    m0 = (r * 8 + walk_x) * BM;
+                }
+                after_epi = true;
+            }
+        }
+        TV_PROBE_DUMP(wave, lane);
+        return;
     } else if constexpr (DMA) {
         constexpr int LA = STAGES - 1;  // K-steps of lookahead
 #pragma unroll
@@ -502,7 +655,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 #endif
             TV_T(1);
 #if TV_GENERIC_BURST
+#ifdef TV_ABL_NO_DMA
+            stage_advance();
+#else
             stage_issue(smem + nxt * STAGE);
+#endif
             compute(smem + cur * STAGE, nullptr, std::false_type{});
 #elif !defined(TV_ABL_NO_DMA)
             compute(smem + cur * STAGE, smem + nxt * STAGE, std::true_type{});
@@ -558,6 +715,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 }
 
 bool g_use_dma = true;
+int g_persist = 0;     // persistent tile walk: 0 off (default: measured -0.3 % over the linear layers, profiles/r03_kernel_experiments.txt item 12), 1 heuristic walk length, n > 1 forced walk of n tiles
 int g_cfg_stages = 0;  // 0 = heuristic, else 2 / 3 / 4
 int g_cfg_bk = 0;      // 0 = largest that divides c_in, else 32 / 64
 int g_addr_mode = 0;   // 0 = buffer DMA when the tensors are < 2 GiB, 1 = force 64-bit global DMA
@@ -592,13 +750,52 @@ int launch_one(const IgemmArgs& a_in, hipStream_t s) {
         IgemmArgs a = a_in;
         a.tiles_m = tiles_m;
         a.xcd_order = (g_xcd_order && a.tiles_n > 1) ? 1 : 0;
+        a.tpb = 1;
+        a.nchunks = a.tiles_n;
+        constexpr bool POK = igemm_persist_ok<BM, BN, WGM, WGN, BK, STAGES, MODE>() && BM == 256 && BN == 256 && BK == 64;
         dim3 grid((unsigned)(a.xcd_order ? 8 * a.tiles_n * ((tiles_m + 7) / 8) : tiles_m * a.tiles_n)), block(WGM * WGN * 64);
+        if constexpr (POK) {
+            // tile walk: W tiles per block, P blocks per XCD label (tpb = W, nchunks = P).  The LDS epilogue parks the tile in the
+            // stage buffers a prefetch would be landing in, ragged row tiles would stage rows past the tensor: one tile per block
+            const int em = epilogue_mode(a);
+            const bool reg_epi = em != 0 || a.form == EF_PLAIN || a.form == EF_GELU_D || a.form == EF_RES_DERIV || a.form == EF_ROPE;
+            const bool single_tap = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.up_shift == 0 && a.dil_mask == 0;
+            if (g_persist != 0 && reg_epi && single_tap && a.M % BM == 0 && a.N % BN == 0) {
+                const int nlist = ((tiles_m + 7) / 8) * a.tiles_n;      // longest per-XCD list
+                int W = (nlist + 31) / 32;                              // 32 block slots per XCD
+                if (g_persist > 1) W = g_persist < nlist ? g_persist : nlist;   // (tuning hook: forced walk length)
+                if (W >= 2) {
+                    a.tpb = W;
+                    a.nchunks = (nlist + W - 1) / W;
+                    grid = dim3((unsigned)(8 * a.nchunks));
+                }
+            }
+        }
         auto go = [&](auto epi) {
             constexpr int EPI_MODE = decltype(epi)::value;
             static TvPerDeviceOnce attr_once;
             if (attr_once.first()) {  // > 64 KiB of dynamic LDS needs the opt-in
                 (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE, EPI_MODE>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+            }
+            if constexpr (POK) {
+                if (a.tpb > 1) {
+                    auto gop = [&](auto form_c) {
+                        constexpr int F = decltype(form_c)::value;
+                        static TvPerDeviceOnce attr_once_p;
+                        if (attr_once_p.first())
+                            (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE, EPI_MODE, true, F>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+                        hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE, EPI_MODE, true, F>), grid, block, BYTES, s, a);
+                    };
+                    if constexpr (EPI_MODE == 1) gop(std::integral_constant<int, EF_RES>{});
+                    else if constexpr (EPI_MODE == 2) gop(std::integral_constant<int, EF_DERIV>{});
+                    else if (a.form == EF_GELU_D) gop(std::integral_constant<int, EF_GELU_D>{});
+                    else if (a.form == EF_RES_DERIV) gop(std::integral_constant<int, EF_RES_DERIV>{});
+                    else if (a.form == EF_ROPE) gop(std::integral_constant<int, EF_ROPE>{});
+                    else gop(std::integral_constant<int, EF_PLAIN>{});
+                    return;
+                }
             }
             hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE, EPI_MODE>), grid, block, BYTES, s, a);
         };
@@ -679,6 +876,11 @@ extern "C" int tv_set_igemm_halo(int on) {   // 0: 3x3 stride-1 convolutions thr
     on %= 10;
     g_use_halo = on != 0;   // 1: heuristic ring depth, 2: ring 2 everywhere, 4: ring 3 wherever it fits
     g_halo_ring = (on == 2) ? 2 : (on == 4 ? 4 : 3);
+    return 0;
+}
+
+extern "C" int tv_set_igemm_persist(int on) {   // tuning hook (A/B timing, tests): see g_persist
+    g_persist = on;
     return 0;
 }
 

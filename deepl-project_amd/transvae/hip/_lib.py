@@ -142,6 +142,10 @@ def load():
         lib.tv_set_igemm_halo.argtypes = [_I]
         lib.tv_set_igemm_epilogue.restype = _I
         lib.tv_set_igemm_epilogue.argtypes = [_I]
+        lib.tv_set_igemm_persist.restype = _I
+        lib.tv_set_igemm_persist.argtypes = [_I]
+        lib.tv_set_attn_bwd_mask.restype = _I
+        lib.tv_set_attn_bwd_mask.argtypes = [_I]
         lib.tv_set_igemm_config.restype = _I          # tuning hooks, not part of the public ABI
         lib.tv_set_igemm_config.argtypes = [_I, _I, _I, _I]
         lib.tv_set_wgrad_stages.restype = _I

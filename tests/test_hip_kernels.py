@@ -753,3 +753,51 @@ def test_register_epilogue_forms_are_bit_identical_to_the_lds_loop(cfg):
     for k in reg:
         assert torch.isfinite(reg[k].float()).all(), k
         assert torch.equal(reg[k], lds[k]), (k, cfg, float((reg[k].float() - lds[k].float()).abs().max()))
+
+
+# ---- persistent column loop of the generic 256 x 256 tile (igemm_nt.hip) ----------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(1024, 384, 1536), (768 + 40, 512, 768), (512, 1536, 1024), (4096, 256, 512), (16384, 256, 2048), (2304, 512, 1280)])
+def test_persistent_column_loop_is_bit_identical_to_one_tile_per_block(M, K, N):
+    """A block of the 256 x 256 tile walks several column tiles of its row tile as one K-loop (the next tile's first stage
+    lands under the epilogue, opened by a counted vmcnt): every register epilogue form must give the bits of the
+    one-tile-per-block launch, on full and ragged row tiles, for the heuristic and for every forced walk length."""
+    from transvae.hip import _lib as L, ops
+    lib = L.load()
+    g = torch.Generator(device=dev()).manual_seed(7)
+    bf = torch.bfloat16
+    x = torch.randn(M, K, device=dev(), generator=g).to(bf)
+    w = torch.randn(N, K, device=dev(), generator=g) * K ** -0.5
+    b = torch.randn(N, device=dev(), generator=g) * 0.1
+    res = torch.randn(M, N, device=dev(), generator=g).to(bf)
+    gz = torch.randn(M, N, device=dev(), generator=g).to(bf)
+    der = torch.rand(M, K, device=dev(), generator=g).to(bf)
+    gres = torch.randn(M, K, device=dev(), generator=g).to(bf)
+    geo = ops._Geo("linear", x, w)
+
+    def cases():
+        out = {}
+        out["plain"] = ops.conv_forward(x, w, b, None, "linear", L.ACT_NONE, False)[0]
+        y, d = ops.conv_forward(x, w, b, None, "linear", L.ACT_GELU, "deriv")[:2]
+        out["gelu+deriv"], out["gelu+deriv:saved"] = y, d
+        out["silu"] = ops.conv_forward(x, w, b, None, "linear", L.ACT_SILU, False)[0]
+        out["residual"] = ops.conv_forward(x, w, b, res, "linear", L.ACT_NONE, False)[0]
+        out["dgrad"] = ops.conv_dgrad(geo, w, gz, x.shape)                     # [M, N] -> [M, K]: K / 256 column tiles
+        out["dgrad*deriv"] = ops.conv_dgrad(geo, w, gz, x.shape, aux=der, aux_act=L.ACT_DERIV)
+        out["(dgrad+res)*deriv"] = ops.conv_dgrad(geo, w, gz, x.shape, residual=gres, aux=der, aux_act=L.ACT_DERIV)
+        return out
+    try:
+        lib.tv_set_igemm_config(256, 256, 0, 0)
+        lib.tv_set_igemm_persist(0)
+        ref = cases()
+        got = {}
+        for walk in (1, 2, 3, 4, 6):
+            lib.tv_set_igemm_persist(walk)
+            got[walk] = cases()
+    finally:
+        lib.tv_set_igemm_persist(1)
+        lib.tv_set_igemm_config(0, 0, 0, 0)
+    for walk, res_w in got.items():
+        for k in ref:
+            assert torch.isfinite(res_w[k].float()).all(), (k, walk)
+            assert torch.equal(res_w[k], ref[k]), (k, walk, float((res_w[k].float() - ref[k].float()).abs().max()))

@@ -30,6 +30,8 @@ linear = len(sys.argv) > 2 and sys.argv[2] == "linear"   # the linear layers of 
 print("library:", L.SO_PATH)
 if os.environ.get("TV_AB_HALO"):
     L.load().tv_set_igemm_halo(int(os.environ["TV_AB_HALO"]))
+if os.environ.get("TV_AB_PERSIST") is not None:    # 0 = one tile per block, 1 = heuristic column walk, n = forced walk
+    L.load().tv_set_igemm_persist(int(os.environ["TV_AB_PERSIST"]))
 if os.environ.get("TV_AB_CFG"):      # bm,bn,stages,bk
     L.load().tv_set_igemm_config(*[int(v) for v in os.environ["TV_AB_CFG"].split(",")])
 g = torch.Generator(device=dev).manual_seed(0)
