@@ -112,7 +112,7 @@ __device__ __forceinline__ constexpr int epi_store_count(bool saves) {
     return MF * (2 * (NC / 2) + (NC & 1)) * (saves ? 2 : 1);
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE, int EPI, bool PERS = false, int PFORM = 0>
+template <int BM, int BN, int WGM, int WGN, int BK, int STAGES, int MODE, int EPI, bool PERS = false, int PFORM = 0, bool P8 = false>
 __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, BK, STAGES>())) void igemm_nt_kernel(const IgemmArgs p) {
     constexpr bool DMA = MODE != 0, BUF = MODE == 2;
     constexpr int NW = WGM * WGN;
@@ -477,7 +477,156 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
     // of a K-step: every wave has read all of stage t (second half issued before the first half's MFMAs), stage t+1 has
     // landed, and stage t's buffer is refilled with stage t+STAGES between the MFMAs that follow.
     constexpr bool PIPE2 = DMA && PIPE_ALL && BK == 64 && !PINGPONG && !TV_NO_PIPE2;
-    if constexpr (PIPE2) {
+    if constexpr (P8) {
+        // ---- eight-phase wave-group ping-pong (round 3; the 256 x 256 tile on single-tap layers) ------------------------------
+        // Ablation of the plain loop on K = 1536 -> N = 6144 (profiles/r03_kernel_experiments.txt item 13): 0.351 ms, without the
+        // DMA issue 0.274, without the fragment reads 0.275, without both 0.204 (= MFMAs + epilogue): the two halves of the data
+        // path cost their full time ON TOP of the matrix work -- all eight waves issue the DMA burst together, read together
+        // and multiply together.  Here a K-step is four phases of 16 MFMAs (one 64 x 32 quadrant of the wave's 128 x 64 tile
+        // over the whole BK), each with its own small load section (4-12 fragment reads, 2 DMA pieces: no burst), and the two
+        // wave groups (waves 0-3 / 4-7 = row halves, partners on every SIMD) run ONE BARRIER APART, so that a SIMD always has
+        // one wave multiplying while the other loads (the structure of the guide's 256-square 8-phase template):
+        //   wave:  [L_k: reads of quadrant k, 2 DMA pieces, waits]  barrier  [M_k: 16 MFMAs at priority 1]  barrier
+        // A stage buffer is four REGIONS, each read in one load section and re-staged (K-step t+2) right behind its last read:
+        //   L1 reads A0 + B0   issues B0 of step t+1   (B0 is read again in L4)
+        //   L2 reads B1        issues A0 of step t+2
+        //   L3 reads A1        issues B1 of step t+2
+        //   L4 reads B0        issues A1 of step t+2,  then vmcnt(6): everything up to B0 of step t+1 has landed
+        // A_a = the 64-row halves a of both groups' rows, B_b = the 32-channel halves b of the four waves' slabs; every wave
+        // issues 2 pieces per region.  Hazards (g0 = waves 0-3, one barrier AHEAD of g1):
+        //   WAR  a region's reads complete (lgkmcnt(0)) BEFORE the barrier that ends their load section; its re-staging DMA
+        //        is issued in the same group's NEXT load section, two barriers later: g1's reads of it are complete too.
+        //   RAW  every wave waits vmcnt in L4(t) before that section's barrier; step t+1 is first read in L1(t+1), two barriers
+        //        later for either group: all eight waves' pieces have landed.
+        // Two tile shapes: 256 x 256 (2 x 4 waves of 128 x 64: quadrants of 4 x 2 fragments, 16 MFMAs each) and 256 x 192
+        // (4 x 2 waves of 64 x 96: row halves of 2 fragments, channel parts of 2 and 4 fragments -- a 32-channel block is the
+        // unit the weight rows of a slab can be cut at -- i.e. phases of 8 / 16 / 16 / 8 MFMAs).  Pieces per wave and K-step:
+        // A_a 2 each, B_0 2 (1), B_1 2: 8 (7); behind B_0 of step t+1 come A_0, B_1, A_1 of step t+2 = 6 pieces either way.
+        static_assert(BM == 256 && (BN == 256 || BN == 192) && NW == 8 && BK == 64 && STAGES == 2 && MODE == 2 && RPI == 8, "8-phase loop: 256-row tiles, 8 waves, BK 64");
+        static_assert(WGM * 2 <= 8 && (WGM == 2 || WGM == 4), "the two wave groups are row halves");
+        constexpr int MH = MF / 2;                 // fragment rows per row half
+        constexpr int NB0 = 2, NB1 = NF - 2;       // fragment columns of the two channel parts (32 channels | the rest)
+        constexpr int PH = WTM / 2 / 8;            // 8-row pieces per (wave row, row half)
+        constexpr int SLAB = WTN / 8, P1 = SLAB - 4;   // pieces per weight slab, of them in part 1
+        constexpr int QB0 = (WGN * 4) / 8;         // pieces per wave of region B_0 (2 or 1)
+        const int grp = wave >> 2;
+        // piece ownership by region: the r-th piece of a region (in row order) belongs to wave r % 8
+        int aq_voff[2][2], aq_lds[2][2], bq_voff[2][2], bq_lds[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = wave + 8 * q;
+                const int j = (r / PH) * (2 * PH) + a * PH + (r % PH);
+                const int row = j * RPI + srow, m = m0 + row;
+                aq_voff[a][q] = (m < p.M) ? (m * p.ldx + (sslot ^ swz_of<BK>(row & 15)) * 8) * 2 : OOB_OFFSET;   // single tap: pixel = m
+                aq_lds[a][q] = j * 1024;
+            }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = wave + 8 * q;
+                const int j = b == 0 ? (r / 4) * SLAB + (r % 4) : (r / P1) * SLAB + 4 + (r % P1);
+                const int row = j * RPI + srow;
+                const int c = (sslot ^ swz_of<BK>(bfrag_reader(row % WTN))) * 8;
+                const int n = n0 + row;
+                bq_voff[b][q] = (n < p.N) ? (n * p.K + c) * 2 : OOB_OFFSET;
+                bq_lds[b][q] = A_BYTES + j * 1024;
+            }
+        auto issue_A = [&](int t, int a) {
+            char* sb = smem + (t & 1) * STAGE;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) buffer_load_lds16(p.x, p.x_bytes, sb + aq_lds[a][q], aq_voff[a][q], t * (BK * 2));
+        };
+        auto issue_B = [&](int t, int b) {
+            char* sb = smem + (t & 1) * STAGE;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (b == 1 || q < QB0) buffer_load_lds16(p.w, p.w_bytes, sb + bq_lds[b][q], bq_voff[b][q], t * (BK * 2));
+        };
+        bf16x8 fa[2][MH], fb[2][NB1 > NB0 ? NB1 : NB0];
+        auto read_A = [&](const char* sb, auto a_c) {
+            constexpr int a = decltype(a_c)::value;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int coff = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+                for (int i = 0; i < MH; ++i) fa[kk][i] = *(const bf16x8*)(sb + a_row_off + (MH * a + i) * 16 * (BK * 2) + coff);
+            }
+        };
+        auto read_B = [&](const char* sb, auto b_c) {
+            constexpr int b = decltype(b_c)::value;
+            constexpr int J0 = b ? NB0 : 0, NJ = b ? NB1 : NB0;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int coff = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[kk][j] = *(const bf16x8*)(sb + b_row_off + bfrag_off(J0 + j) * (BK * 2) + coff);
+            }
+        };
+        auto close_load = [&]() {   // my reads are complete (data ready, region free for its next DMA), then the phase barrier
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mfma_q = [&](auto a_c, auto b_c) {
+            constexpr int a = decltype(a_c)::value, b = decltype(b_c)::value;
+            constexpr int J0 = b ? NB0 : 0, NJ = b ? NB1 : NB0;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MH; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[MH * a + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[MH * a + i][J0 + j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        // prologue: step 0 whole, of step 1 everything but B0 (the steady-state order)
+        issue_A(0, 0); issue_B(0, 0); issue_B(0, 1); issue_A(0, 1);
+        if (nk > 1) { issue_A(1, 0); issue_B(1, 1); issue_A(1, 1); wait_vmcnt<6>(); }
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();               // step 0 has landed for every wave
+        if (grp == 1) __builtin_amdgcn_s_barrier(); // group 1 runs one barrier behind
+        for (int t = 0; t < nk; ++t) {
+            const char* sb = smem + (t & 1) * STAGE;
+            // phase 1: quadrant (0, 0)
+            read_B(sb, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            read_A(sb, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < nk) issue_B(t + 1, 0);
+            close_load();
+            mfma_q(I0{}, I0{});
+            // phase 2: quadrant (0, 1)
+            read_B(sb, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nk) issue_A(t + 2, 0);
+            close_load();
+            mfma_q(I0{}, I1{});
+            // phase 3: quadrant (1, 1)
+            read_A(sb, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nk) issue_B(t + 2, 1);
+            close_load();
+            mfma_q(I1{}, I1{});
+            // phase 4: quadrant (1, 0)
+            read_B(sb, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nk) { issue_A(t + 2, 1); wait_vmcnt<6>(); }   // B0 of step t+1 and everything older has landed
+            else if (t + 1 < nk) wait_vmcnt<0>();
+            close_load();
+            mfma_q(I1{}, I0{});
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+    } else if constexpr (PIPE2) {
         bf16x8 f0a[MF], f0b[NF], f1a[MF], f1b[NF];
         auto read_half = [&](const char* sbase, int kk, bf16x8 (&fa)[MF], bf16x8 (&fb)[NF]) {
             const int coff = ((kk * 4 + fq) ^ sw) * 16;
@@ -715,6 +864,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 }
 
 bool g_use_dma = true;
+int g_loop8 = 1;       // eight-phase ping-pong loop for single-tap layers on the 256 x 256 tile (tv_set_igemm_persist(-1 / -2): off / on)
 int g_persist = 0;     // persistent tile walk: 0 off (default: measured -0.3 % over the linear layers, profiles/r03_kernel_experiments.txt item 12), 1 heuristic walk length, n > 1 forced walk of n tiles
 int g_cfg_stages = 0;  // 0 = heuristic, else 2 / 3 / 4
 int g_cfg_bk = 0;      // 0 = largest that divides c_in, else 32 / 64
@@ -794,6 +944,17 @@ int launch_one(const IgemmArgs& a_in, hipStream_t s) {
                     else if (a.form == EF_RES_DERIV) gop(std::integral_constant<int, EF_RES_DERIV>{});
                     else if (a.form == EF_ROPE) gop(std::integral_constant<int, EF_ROPE>{});
                     else gop(std::integral_constant<int, EF_PLAIN>{});
+                    return;
+                }
+            }
+            if constexpr (BM == 256 && ((BN == 256 && WGM == 2 && WGN == 4) || (BN == 192 && WGM == 4 && WGN == 2)) && BK == 64 && STAGES == 2 && MODE == 2) {
+                const bool single_tap8 = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.up_shift == 0 && a.dil_mask == 0;
+                if (g_loop8 && single_tap8) {   // 1x1 / linear layers: the eight-phase ping-pong loop
+                    static TvPerDeviceOnce attr_once_8;
+                    if (attr_once_8.first())
+                        (void)hipFuncSetAttribute((const void*)igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE, EPI_MODE, false, 0, true>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+                    hipLaunchKernelGGL((igemm_nt_kernel<BM, BN, WGM, WGN, BK, STAGES, MODE, EPI_MODE, false, 0, true>), grid, block, BYTES, s, a);
                     return;
                 }
             }
@@ -879,8 +1040,10 @@ extern "C" int tv_set_igemm_halo(int on) {   // 0: 3x3 stride-1 convolutions thr
     return 0;
 }
 
-extern "C" int tv_set_igemm_persist(int on) {   // tuning hook (A/B timing, tests): see g_persist
-    g_persist = on;
+extern "C" int tv_set_igemm_persist(int on) {   // tuning hook (A/B timing, tests): see g_persist; -1 / -2: eight-phase loop off / on
+    if (on == -1) g_loop8 = 0;
+    else if (on == -2) g_loop8 = 1;
+    else g_persist = on;
     return 0;
 }
 

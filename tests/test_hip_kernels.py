@@ -801,3 +801,43 @@ def test_persistent_column_loop_is_bit_identical_to_one_tile_per_block(M, K, N):
         for k in ref:
             assert torch.isfinite(res_w[k].float()).all(), (k, walk)
             assert torch.equal(res_w[k], ref[k]), (k, walk, float((res_w[k].float() - ref[k].float()).abs().max()))
+
+
+# ---- eight-phase ping-pong loop of the 256 x 256 tile (igemm_nt.hip, single-tap layers) ------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("bn", [256, 192])
+@pytest.mark.parametrize("M,K,N", [(1024, 64, 768), (1024, 128, 1536), (768 + 40, 192, 768), (512, 1536, 768), (4096, 320, 1536),
+                                   (16384, 384, 1536), (1000, 448, 384)])
+def test_eight_phase_loop_is_bit_identical_to_the_plain_loop(M, K, N, bn):
+    """The 256 x 256 tile runs 1x1 / linear layers through a four-phases-per-K-step wave-group ping-pong (regions of a stage
+    buffer re-staged right behind their last read, counted vmcnt once per K-step): every epilogue form must give the bits of
+    the plain two-stage loop -- K of one, two, an odd number and many steps, full and ragged row tiles."""
+    from transvae.hip import _lib as L, ops
+    lib = L.load()
+    g = torch.Generator(device=dev()).manual_seed(11)
+    bf = torch.bfloat16
+    x = torch.randn(M, K, device=dev(), generator=g).to(bf)
+    w = torch.randn(N, K, device=dev(), generator=g) * K ** -0.5
+    b = torch.randn(N, device=dev(), generator=g) * 0.1
+    res = torch.randn(M, N, device=dev(), generator=g).to(bf)
+
+    def cases():
+        out = {}
+        out["plain"] = ops.conv_forward(x, w, b, None, "linear", L.ACT_NONE, False)[0]
+        y, d = ops.conv_forward(x, w, b, None, "linear", L.ACT_GELU, "deriv")[:2]
+        out["gelu+deriv"], out["gelu+deriv:saved"] = y, d
+        out["residual"] = ops.conv_forward(x, w, b, res, "linear", L.ACT_NONE, False)[0]
+        return out
+    try:
+        lib.tv_set_igemm_config(256, bn, 0, 0)   # (256 x 256 and 256 x 192 tiles: N is a multiple of 192 here, and of 256 but once)
+        lib.tv_set_igemm_persist(-1)
+        ref = cases()
+        lib.tv_set_igemm_persist(-2)
+        got = [cases() for _ in range(3)]     # (repeated: a race in the hand-placed waits would come and go)
+    finally:
+        lib.tv_set_igemm_persist(-2)
+        lib.tv_set_igemm_config(0, 0, 0, 0)
+    for r in got:
+        for k in ref:
+            assert torch.isfinite(r[k].float()).all(), k
+            assert torch.equal(r[k], ref[k]), (k, float((r[k].float() - ref[k].float()).abs().max()))
