@@ -227,6 +227,110 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
         issue_b(b_buf, 0, 0);
         issue_b(b_buf + B_BYTES, 1, 0);
         wait_vmcnt<0>();
+#if TV_HALO_P8
+        // Round 3: a tap step in FOUR phases of 12 MFMAs (quadrants: 2 fragment rows x 3 fragment columns x both halves of
+        // BK), each with its own small load section -- 4-10 fragment reads and ONE DMA piece -- instead of one load phase of 20
+        // reads + a burst of 3-4 pieces against one MFMA phase of 48: the pieces of a burst queue at the address pipe
+        // (~150 wave-cycles each against ~60 alone; the ablation of the two-phase form: 2.19 ms, DMA issue off 1.54), which made
+        // the load phase longer than the partner's MFMA phase.  Same ping-pong (group 1 one barrier behind), same ring, same
+        // counted wait (at the end of the step's last load section), same results bit for bit; the structure that took the
+        // generic 256-row tiles from 0.345 to 0.307 ms (igemm_nt.hip, eight-phase loop).
+        //   L1 reads A0 + B_lo, issues weight piece 0 | L2 reads B_hi, piece 1 | L3 reads A1, piece 2 | L4 reads B_lo, halo piece, wait
+        //   hazards: the slot of slab t+2 was last read in L4 of step t-1 by either group, complete (lgkmcnt) before the barrier
+        //   that ends that section; the same group's L1 of step t follows two barriers later.
+        static_assert(MF % 2 == 0 && NF % 2 == 0 && B_IT <= 3 && TV_PP_NM == 0, "halo eight-phase loop: one weight piece per load section");
+        constexpr int MH = MF / 2, NH = NF / 2;
+        __builtin_amdgcn_s_barrier();                 // the prologue's pieces have landed for every wave
+        if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one barrier behind
+        int bcur = 0;
+        bf16x8 qa[2][MH], qb[2][NH];
+        for (int ch = 0; ch < cch; ++ch) {
+            const char* acur = a_buf + (ch & 1) * A_BYTES;
+            char* anxt = a_buf + ((ch + 1) & 1) * A_BYTES;
+            const bool more = ch + 1 < cch;
+            static_for<0, 9>([&](auto tap_c) {
+                constexpr int tap = decltype(tap_c)::value;
+                constexpr int toff = (tap / 3) * HWD + (tap % 3);
+                const char* const bslot = b_buf + bcur * B_BYTES;
+                char* const bfill = b_buf + ((bcur + 2 >= BST) ? bcur + 2 - BST : bcur + 2) * B_BYTES;
+                const bool b_go = (tap + 2 < 9) || more;
+                const int b_koff = ((tap + 2 < 9) ? (tap + 2) * p.c_in + ch * BK : (tap + 2 - 9) * p.c_in + (ch + 1) * BK) * 2;
+                int hpb = hp_base;
+                asm volatile("" : "+v"(hpb));   // pin the address arithmetic to this tap
+                auto rd_a = [&](auto a_c) {
+                    constexpr int a = decltype(a_c)::value;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < MH; ++i) {
+                            const int hp = hpb + (MH * a + i) * HWD + toff;
+                            qa[kk][i] = *(const bf16x8*)(acur + hp * (BK * 2) + (((kk * 4 + fq) ^ (hp & 7)) << 4));
+                        }
+                };
+                auto rd_b = [&](auto b_c) {
+                    constexpr int b = decltype(b_c)::value;
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const int coff = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+                        for (int j = 0; j < NH; ++j) qb[kk][j] = *(const bf16x8*)(bslot + b_row_off + bfrag_off(NH * b + j) * (BK * 2) + coff);
+                    }
+                };
+                auto close_load = [&]() {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                auto mm = [&](auto a_c, auto b_c) {
+                    constexpr int a = decltype(a_c)::value, b = decltype(b_c)::value;
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < MH; ++i)
+#pragma unroll
+                            for (int j = 0; j < NH; ++j)
+                                acc[MH * a + i][NH * b + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb[kk][j], qa[kk][i], acc[MH * a + i][NH * b + j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                using I0 = std::integral_constant<int, 0>;
+                using I1 = std::integral_constant<int, 1>;
+                rd_b(I0{});
+                __builtin_amdgcn_sched_barrier(0);
+                rd_a(I0{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (0 < B_IT && b_go) issue_b_piece(bfill, 0 < B_IT ? 0 : 0, b_koff);
+                close_load();
+                mm(I0{}, I0{});
+                rd_b(I1{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (1 < B_IT && b_go) issue_b_piece(bfill, 1 < B_IT ? 1 : 0, b_koff);
+                close_load();
+                mm(I0{}, I1{});
+                rd_a(I1{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (2 < B_IT && b_go) issue_b_piece(bfill, 2 < B_IT ? 2 : 0, b_koff);
+                close_load();
+                mm(I1{}, I1{});
+                rd_b(I0{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap < ATAPS && tap < A_IT && more) issue_a(anxt, tap, ch + 1);
+                // in flight may stay, in issue order: [the previous step's halo piece] [this step's weight pieces] [this step's
+                // halo piece]: the slab of the NEXT step (issued one step ago) has landed
+                if (more) wait_vmcnt<nsure(tap - 1) + B_IT + nsure(tap)>();
+                else if (tap + 2 < 9) wait_vmcnt<B_IT>();
+                else wait_vmcnt<0>();
+                close_load();
+                mm(I1{}, I0{});
+                bcur = (bcur + 1 == BST) ? 0 : bcur + 1;
+            });
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();   // (both groups have passed the same number of barriers)
+#else
         if (grp == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one phase behind
         int bcur = 0;
         for (int ch = 0; ch < cch; ++ch) {
@@ -336,6 +440,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
             });
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();   // (both groups have passed the same number of barriers)
+#endif
     } else if constexpr (PIPE_ALL && !TV_NO_PIPE2) {
         // Register-pipelined like the generic kernel: two half-step (32-deep) fragment sets per wave; the block barrier sits
         // between the halves of a step, when every wave has read all of step t.  After it the weight slot of step t is
