@@ -87,6 +87,9 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 #ifndef TV_ATTN_V_LATE
 #define TV_ATTN_V_LATE 0
 #endif
+#ifndef TV_ATTN_FWD64
+#define TV_ATTN_FWD64 2048  // forward: sequences of at least this many tokens take the 64-queries-per-wave kernel (0 = never): N = 4096 1.745 -> 1.693 ms, N = 1024 equal
+#endif
 #ifndef TV_ATTN_DELTA_MFMA
 #define TV_ATTN_DELTA_MFMA 1  // dq: -delta enters dP through one extra k-step (three bf16 pieces = fp32), not 16 v_add_f32 per tile
 #endif
@@ -551,6 +554,202 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, 64 queries per wave (TV_ATTN_FWD64): block = 4 waves x 64 queries = 256 queries.
+// Ablation of the 32-query kernel (profiles/r03_kernel_experiments.txt item 11): without its LDS fragment reads it runs 31 %
+// faster, without the DMA issue 15 % -- a wave with 32 queries needs one K / V fragment from LDS per MFMA.  Here a wave holds
+// TWO query tiles (a, b): a K fragment (and a V^T fragment) read once feeds two MFMAs, and a block stages the same K / V
+// bytes for twice the matrix work.  The 64-key stage is walked as two 32-key halves so that only two S tiles are alive
+// (one per query tile): registers ~190, two blocks per CU.
+// ------------------------------------------------------------------------------------------------
+template <int BLOCK_Q>
+__device__ __forceinline__ bool attn_block_q(const AttnArgs& p, int& tile, int& head, int& b) {
+    const int tiles = (p.N + BLOCK_Q - 1) / BLOCK_Q;
+    const int lin = blockIdx.x, j = lin >> 3;
+    tile = j % tiles;
+    const int hb = (j / tiles) * 8 + (lin & 7);
+    if (hb >= p.heads * p.B) return false;
+    head = hb % p.heads;
+    b = hb / p.heads;
+    return true;
+}
+
+#ifndef TV_ATTN_FWD64_OCC
+#define TV_ATTN_FWD64_OCC 3   // waves per SIMD the register allocation must leave room for (176 registers / 2 waves: 1.813 ms; capped at 168 / 3 waves, 7 dwords spilled: 1.693 ms)
+#endif
+__global__ __launch_bounds__(256, TV_ATTN_FWD64_OCC) void attn_fwd64_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // TV_ATTN_NS stages x (K 8 KiB + V 8 KiB)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_x, head, b;
+    if (!attn_block_q<256>(p, tile_x, head, b)) return;
+    const int C = p.heads * 64;
+    const size_t ld = (size_t)3 * C;
+    const bf16* qbase = p.qkv + (size_t)b * p.N * ld + head * 64;
+    const bf16* kbase = qbase + C;
+    const bf16* vbase = qbase + 2 * C;
+    const int q0 = tile_x * 256 + wave * 64;
+    const int h = lane >> 5;
+    int qi[2];
+    bool q_ok[2];
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        qi[u] = q0 + 32 * u + (lane & 31);
+        q_ok[u] = qi[u] < p.N;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (q_ok[u]) v = *(const bf16x8*)(qbase + (size_t)qi[u] * ld + 16 * st + 8 * h);
+            qf[u][st] = v;
+        }
+    }
+    f32x16 ot[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ot[u][0][i] = ot[u][1][i] = 0.f;
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    const float c2 = p.scale * 1.4426950408889634f;
+    const int nblk = (p.N + 63) / 64;
+
+    int off_k[4], off_v[2], off_vh[2];
+    rows_offsets(lane, off_k);
+    cols_offsets<true>(lane, off_v, off_vh);
+    const unsigned smem_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const char* abs_k[4];
+    unsigned abs_v[2], abs_vh[2];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) abs_k[st] = smem + off_k[st];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        abs_v[db] = smem_addr + off_v[db];
+        abs_vh[db] = smem_addr + off_vh[db];
+    }
+    int vo_k[2], vo_v[2];
+    stage_offsets<false>(vo_k, (int)ld, wave, lane);
+    stage_offsets<true>(vo_v, (int)ld, wave, lane);
+    const unsigned kv_bytes = stage_extent(p.N, (int)ld);
+    constexpr int NS = TV_ATTN_NS, D = NS - 1;
+    constexpr int PIECES = 4;
+    auto stage = [&](int t, char* sb) {
+        stage_rows_buf(sb, kbase, kv_bytes, t * 64, (int)ld, vo_k, wave);
+        stage_rows_buf(sb + KV_TILE, vbase, kv_bytes, t * 64, (int)ld, vo_v, wave);
+    };
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+        if (i < nblk) stage(i, smem + i * 2 * KV_TILE);
+    // 32 keys (half KT of the stage's 64) against both query tiles
+    auto half_block = [&](int t, auto stage_c, auto kt_c) {
+        constexpr int S = decltype(stage_c)::value, KT = decltype(kt_c)::value;
+        constexpr int KB = S * 2 * KV_TILE + KT * 32 * 128, VB = S * 2 * KV_TILE + KV_TILE + KT * 32 * 128;
+        f32x16 s[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[0][i] = s[1][i] = 0.f;
+        {
+            const bf16x8 k0 = read_rows_imm<KB>(abs_k[0]), k1 = read_rows_imm<KB>(abs_k[1]);
+            const bf16x8 k2 = read_rows_imm<KB>(abs_k[2]), k3 = read_rows_imm<KB>(abs_k[3]);
+            s[0] = mfma32(k0, qf[0][0], s[0]);
+            s[1] = mfma32(k0, qf[1][0], s[1]);
+            s[0] = mfma32(k1, qf[0][1], s[0]);
+            s[1] = mfma32(k1, qf[1][1], s[1]);
+            s[0] = mfma32(k2, qf[0][2], s[0]);
+            s[1] = mfma32(k2, qf[1][2], s[1]);
+            s[0] = mfma32(k3, qf[0][3], s[0]);
+            s[1] = mfma32(k3, qf[1][3], s[1]);
+        }
+        if constexpr (KT == 0) {   // the next stage's DMA pieces in the shadow of the first S MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(TV_ATTN_ABL & 8) && t + D < nblk) stage(t + D, smem + ((S + D) % NS) * 2 * KV_TILE);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bf16x8 vfr[2][2];   // V^T fragments of these 32 keys: [16-key half][d block]
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            vfr[0][db] = read_cols_imm<VB + 0 * 128>(abs_v[db], abs_vh[db]);
+            vfr[1][db] = read_cols_imm<VB + 16 * 128>(abs_v[db], abs_vh[db]);
+        }
+        const int kv0 = t * 64 + KT * 32;
+        if (kv0 + 32 > p.N) {   // ragged end of the sequence: mask keys >= N (wave-uniform branch)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (key >= p.N) s[u][r] = -INFINITY;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[u][r]);
+            mloc = xhalf_max(mloc);
+            // (a half-block whose 32 keys are all masked leaves mloc = -inf: no rescale, p = exp2(-inf) = 0)
+#if TV_ATTN_LAZY > 0
+            const bool need = __any((mloc - m[u]) * c2 > (float)TV_ATTN_LAZY);
+#else
+            const bool need = __any(mloc > m[u]);
+#endif
+            if (need) {
+                const float mnew = fmaxf(m[u], mloc);
+                const float alpha = fexp2((m[u] - mnew) * c2);
+                m[u] = mnew;
+                l[u] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    ot[u][0][i] *= alpha;
+                    ot[u][1][i] *= alpha;
+                }
+            }
+            const float mc = m[u] * c2;
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fexp2(fmaf(s[u][r], c2, -mc));
+                s[u][r] = pv;
+                rs += pv;
+            }
+            l[u] += rs;
+        }
+        lds_wait_all();
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const bf16x8 pa = pack_acc(s[0], ss), pb = pack_acc(s[1], ss);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                ot[0][db] = mfma32b(vfr[ss][db], pa, ot[0][db]);
+                ot[1][db] = mfma32b(vfr[ss][db], pb, ot[1][db]);
+            }
+        }
+    };
+    auto key_block = [&](int t, auto stage_c) {
+        if (t + D - 1 < nblk) vm_wait<PIECES * (D - 1)>();
+        else vm_wait<0>();
+        block_sync();
+        half_block(t, stage_c, ic<0>{});
+        if (t * 64 + 32 < p.N) half_block(t, stage_c, ic<1>{});
+    };
+    ring_for<NS>(nblk, key_block);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float lt = xhalf_sum(l[u]);
+        if (q_ok[u]) {
+            const float inv = 1.0f / lt;
+            bf16* orow = p.out + ((size_t)b * p.N + qi[u]) * C + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 v = {(bf16)(ot[u][db][4 * g] * inv), (bf16)(ot[u][db][4 * g + 1] * inv), (bf16)(ot[u][db][4 * g + 2] * inv),
+                                (bf16)(ot[u][db][4 * g + 3] * inv)};
+                    *(bf16x4*)(orow + db * 32 + 8 * g + 4 * h) = v;
+                }
+            if (h == 0) p.lse[((size_t)b * p.heads + head) * p.N + qi[u]] = (m[u] * c2 + __log2f(lt)) * 0.6931471805599453f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // delta[b][head][q] = sum_d dO[q][d] * O[q][d]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnArgs p) {
@@ -949,6 +1148,14 @@ extern "C" int tv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, i
     AttnArgs a{};
     a.qkv = (const bf16*)qkv; a.out = (bf16*)o; a.lse = lse; a.zeros = (const char*)tv_zero_page();
     a.B = B; a.N = N; a.heads = heads; a.scale = scale;
+#if TV_ATTN_FWD64
+    if (N >= TV_ATTN_FWD64) {   // long sequences: 64 queries per wave (half the LDS fragment reads and DMA pieces per MFMA)
+        dim3 grid64((unsigned)(8 * tv_cdiv(N, 256) * tv_cdiv((long long)heads * B, 8)));
+        hipLaunchKernelGGL(attn_fwd64_kernel, grid64, dim3(256), TV_ATTN_NS * 2 * KV_TILE, (hipStream_t)stream, a);
+        TV_CHECK_LAUNCH("tv_attn_fwd");
+        return TV_OK;
+    }
+#endif
     dim3 grid((unsigned)(8 * tv_cdiv(N, 128) * tv_cdiv((long long)heads * B, 8)));
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), TV_ATTN_NS * 2 * KV_TILE, (hipStream_t)stream, a);
     TV_CHECK_LAUNCH("tv_attn_fwd");

@@ -84,6 +84,9 @@ using namespace tvi;
 #ifndef TV_HALO_PP
 #define TV_HALO_PP 1       // wave-group ping-pong main loop of the 8-wave halo tiles with a 3-deep weight ring (see conv3x3_halo_kernel):
 #endif                     // +8-10 % on the 192-channel 3x3 layers over the lockstep pipelined loop (tools/probes/ab_lib.py)
+#ifndef TV_P8_B0PF
+#define TV_P8_B0PF 1       // eight-phase GEMM loop: B0 fragments resident for both of their quadrants, the next K-step's read in phase 4
+#endif
 #ifndef TV_HALO_P8
 #define TV_HALO_P8 0       // halo ping-pong loop in four phases of 12 MFMAs per tap step (one DMA piece per load section) instead of two: measured 8-11 % SLOWER (profiles/r03_kernel_experiments.txt item 15), kept for A/B
 #endif

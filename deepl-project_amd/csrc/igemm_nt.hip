@@ -545,7 +545,11 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
             for (int q = 0; q < 2; ++q)
                 if (b == 1 || q < QB0) buffer_load_lds16(p.w, p.w_bytes, sb + bq_lds[b][q], bq_voff[b][q], t * (BK * 2));
         };
-        bf16x8 fa[2][MH], fb[2][NB1 > NB0 ? NB1 : NB0];
+        // Fragment registers: one A half at a time; B0 stays resident for its two quadrants (phases 1 and 4) and B0 of the NEXT
+        // K-step is read in phase 4 into a second set (TV_P8_B0PF; balances the load sections: 8 / 4 / 8 / 4 reads on the
+        // 256 x 256 tile instead of 12 / 4 / 8 / 4): for that the wait that retires step t+1 sits in L3 -- behind B0 of step
+        // t+1 come only A0 and B1 of step t+2 then: vmcnt(4) -- and L4 reads two barriers later.
+        bf16x8 fa[2][MH], fb0[2][2][NB0], fb1[2][NB1];
         auto read_A = [&](const char* sb, auto a_c) {
             constexpr int a = decltype(a_c)::value;
 #pragma unroll
@@ -555,14 +559,21 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
                 for (int i = 0; i < MH; ++i) fa[kk][i] = *(const bf16x8*)(sb + a_row_off + (MH * a + i) * 16 * (BK * 2) + coff);
             }
         };
-        auto read_B = [&](const char* sb, auto b_c) {
-            constexpr int b = decltype(b_c)::value;
-            constexpr int J0 = b ? NB0 : 0, NJ = b ? NB1 : NB0;
+        auto read_B0 = [&](const char* sb, auto set_c) {
+            constexpr int S = decltype(set_c)::value;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int coff = ((kk * 4 + fq) ^ sw) * 16;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) fb[kk][j] = *(const bf16x8*)(sb + b_row_off + bfrag_off(J0 + j) * (BK * 2) + coff);
+                for (int j = 0; j < NB0; ++j) fb0[S][kk][j] = *(const bf16x8*)(sb + b_row_off + bfrag_off(j) * (BK * 2) + coff);
+            }
+        };
+        auto read_B1 = [&](const char* sb) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int coff = ((kk * 4 + fq) ^ sw) * 16;
+#pragma unroll
+                for (int j = 0; j < NB1; ++j) fb1[kk][j] = *(const bf16x8*)(sb + b_row_off + bfrag_off(NB0 + j) * (BK * 2) + coff);
             }
         };
         auto close_load = [&]() {   // my reads are complete (data ready, region free for its next DMA), then the phase barrier
@@ -571,8 +582,8 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto mfma_q = [&](auto a_c, auto b_c) {
-            constexpr int a = decltype(a_c)::value, b = decltype(b_c)::value;
+        auto mfma_q = [&](auto a_c, auto b_c, auto set_c) {
+            constexpr int a = decltype(a_c)::value, b = decltype(b_c)::value, S = decltype(set_c)::value;
             constexpr int J0 = b ? NB0 : 0, NJ = b ? NB1 : NB0;
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -580,8 +591,12 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 #pragma unroll
                 for (int i = 0; i < MH; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[MH * a + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[MH * a + i][J0 + j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) {
+                        bf16x8 bv;
+                        if constexpr (b == 0) bv = fb0[S][kk][j < NB0 ? j : 0];
+                        else bv = fb1[kk][j < NB1 ? j : 0];
+                        acc[MH * a + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv, fa[kk][i], acc[MH * a + i][J0 + j], 0, 0, 0);
+                    }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -594,36 +609,60 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
         if (nk > 1) { issue_A(1, 0); issue_B(1, 1); issue_A(1, 1); wait_vmcnt<6>(); }
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();               // step 0 has landed for every wave
+#if TV_P8_B0PF
+        read_B0(smem, I0{});                        // B0 of step 0 (its region is re-staged in L1 of step 1 at the earliest)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         if (grp == 1) __builtin_amdgcn_s_barrier(); // group 1 runs one barrier behind
-        for (int t = 0; t < nk; ++t) {
+        // one K-step with B0 in register set S (the next step's goes to set 1 - S)
+        auto kstep = [&](int t, auto set_c) {
+            constexpr int S = decltype(set_c)::value;
+            using SC = std::integral_constant<int, TV_P8_B0PF ? S : 0>;
+            using SN = std::integral_constant<int, TV_P8_B0PF ? 1 - S : 0>;
             const char* sb = smem + (t & 1) * STAGE;
             // phase 1: quadrant (0, 0)
-            read_B(sb, I0{});
+#if !TV_P8_B0PF
+            read_B0(sb, SC{});
             __builtin_amdgcn_sched_barrier(0);
+#endif
             read_A(sb, I0{});
             __builtin_amdgcn_sched_barrier(0);
             if (t + 1 < nk) issue_B(t + 1, 0);
             close_load();
-            mfma_q(I0{}, I0{});
+            mfma_q(I0{}, I0{}, SC{});
             // phase 2: quadrant (0, 1)
-            read_B(sb, I1{});
+            read_B1(sb);
             __builtin_amdgcn_sched_barrier(0);
             if (t + 2 < nk) issue_A(t + 2, 0);
             close_load();
-            mfma_q(I0{}, I1{});
+            mfma_q(I0{}, I1{}, SC{});
             // phase 3: quadrant (1, 1)
             read_A(sb, I1{});
             __builtin_amdgcn_sched_barrier(0);
             if (t + 2 < nk) issue_B(t + 2, 1);
+#if TV_P8_B0PF
+            if (t + 2 < nk) wait_vmcnt<4>();         // behind B0 of step t+1: A0, B1 of step t+2 -> step t+1 has landed
+            else if (t + 1 < nk) wait_vmcnt<0>();
+#endif
             close_load();
-            mfma_q(I1{}, I1{});
+            mfma_q(I1{}, I1{}, SC{});
             // phase 4: quadrant (1, 0)
-            read_B(sb, I0{});
+#if TV_P8_B0PF
+            if (t + 1 < nk) read_B0(smem + ((t + 1) & 1) * STAGE, SN{});   // next step's B0: two barriers behind every wave's wait
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nk) issue_A(t + 2, 1);
+#else
+            read_B0(sb, SC{});
             __builtin_amdgcn_sched_barrier(0);
             if (t + 2 < nk) { issue_A(t + 2, 1); wait_vmcnt<6>(); }   // B0 of step t+1 and everything older has landed
             else if (t + 1 < nk) wait_vmcnt<0>();
+#endif
             close_load();
-            mfma_q(I1{}, I0{});
+            mfma_q(I1{}, I0{}, SC{});
+        };
+        for (int t = 0; t < nk; t += 2) {
+            kstep(t, I0{});
+            if (t + 1 < nk) kstep(t + 1, I1{});
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
     } else if constexpr (PIPE2) {

@@ -668,7 +668,8 @@ def test_qkv_projection_with_rope_in_the_epilogue_and_adjoint_in_attention_backw
 
 
 @pytest.mark.parametrize("B,H,W,heads,rope", [(2, 8, 8, 2, True), (1, 16, 12, 1, True), (2, 4, 4, 3, False),
-                                              (1, 16, 16, 2, True), (1, 15, 20, 1, True), (1, 32, 32, 2, True)])
+                                              (1, 16, 16, 2, True), (1, 15, 20, 1, True), (1, 32, 32, 2, True),
+                                              (1, 48, 45, 1, True), (2, 64, 32, 1, False)])   # N >= 2048: the 64-queries-per-wave forward kernel (ragged / whole)
 def test_attention_fwd_bwd(B, H, W, heads, rope):
     from oracle import transvae_oracle as O
     from oracle import filler
