@@ -73,7 +73,7 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 #define TV_ATTN_NS 3        // forward, dq: stages of K 8 KiB + V 8 KiB (3 blocks of 48 KiB per CU)
 #endif
 #ifndef TV_ATTN_NS_DKV
-#define TV_ATTN_NS_DKV 3    // dk / dv: stages of Q 4 KiB + dO 4 KiB + 256 B
+#define TV_ATTN_NS_DKV 2    // dk / dv: ring stages of TV_ATTN_DKV_QS x (Q 4 KiB + dO 4 KiB + 256 B); with two tiles per stage a ring of 2 measured best (3.17 -> 3.09-3.12 ms at N = 4096)
 #endif
 #ifndef TV_ATTN_SUM_MFMA
 #define TV_ATTN_SUM_MFMA 0  // forward: softmax row sums on the matrix pipe (an all-ones A operand) instead of 32 v_add_f32 per key block: measured 2.7 % SLOWER, off
@@ -956,8 +956,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 // dk / dv: block = 4 waves x 32 keys (key on the lane), loops over 32-query tiles.
 // LDS stage: Q tile [32][64] (4 KiB), dO tile [32][64] (4 KiB), lse[32] + delta[32] fp32 (256 B)
 // ------------------------------------------------------------------------------------------------
-constexpr int QT_TILE = 32 * 128;
-constexpr int DKV_STAGE = 2 * QT_TILE + 256;
+#ifndef TV_ATTN_DKV_QS
+#define TV_ATTN_DKV_QS 2     // 32-query tiles per ring stage of the dk / dv kernel (one barrier and one DMA wait per stage)
+#endif
+constexpr int DKV_QS = TV_ATTN_DKV_QS;
+constexpr int QT_TILE = DKV_QS * 32 * 128;
+constexpr int DKV_STAGE = 2 * QT_TILE + DKV_QS * 256;
 
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -993,22 +997,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) dkt[0][i] = dkt[1][i] = dvt[0][i] = dvt[1][i] = 0.f;
     const float c2 = p.scale * 1.4426950408889634f;
-    const int ntile = (p.N + 31) / 32;
+    const int ntile = (p.N + 32 * DKV_QS - 1) / (32 * DKV_QS);   // ring stages of DKV_QS 32-query tiles
     int off_r[4], off_c[2], off_ch[2];
     rows_offsets(lane, off_r);
     cols_offsets<false>(lane, off_c, off_ch);
 
-    int vo_q[1], vo_g[1];
+    int vo_q[DKV_QS], vo_g[DKV_QS];
     stage_offsets<false>(vo_q, (int)ld, wave, lane);
     stage_offsets<false>(vo_g, C, wave, lane);
     const unsigned q_bytes = stage_extent(p.N, (int)ld), g_bytes = stage_extent(p.N, C);
     auto stage = [&](int t, char* sb) {
-        stage_rows_buf(sb, qbase, q_bytes, t * 32, (int)ld, vo_q, wave);
-        stage_rows_buf(sb + QT_TILE, gbase, g_bytes, t * 32, C, vo_g, wave);
-        if (wave == 0) {  // lanes 0-31: lse, lanes 32-63: delta (4-byte LDS-DMA)
-            const int q = t * 32 + (lane & 31);
+        stage_rows_buf(sb, qbase, q_bytes, t * 32 * DKV_QS, (int)ld, vo_q, wave);
+        stage_rows_buf(sb + QT_TILE, gbase, g_bytes, t * 32 * DKV_QS, C, vo_g, wave);
+        if (wave < DKV_QS) {  // wave u: statistics of the stage's tile u -- lanes 0-31: lse, lanes 32-63: delta (4-byte LDS-DMA)
+            const int q = (t * DKV_QS + wave) * 32 + (lane & 31);
             const float* src = (q < p.N) ? ((lane < 32 ? lse_b : del_b) + q) : (const float*)(p.zeros + lane * 4);
-            __builtin_amdgcn_global_load_lds(TV_GLB(src), TV_LDS(sb + 2 * QT_TILE), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(TV_GLB(src), TV_LDS(sb + 2 * QT_TILE + wave * 256), 4, 0, 0);
         }
     };
 
@@ -1022,37 +1026,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         abs_c[db] = smem_addr + off_c[db];
         abs_ch[db] = smem_addr + off_ch[db];
     }
-    const char* abs_st = smem + 2 * QT_TILE + 16 * h;      // this lane half's part of the lse / delta rows
+    const char* abs_st = smem + 16 * h;      // this lane half's part of the lse / delta rows (the stage and tile offsets are immediates)
     constexpr int NS = TV_ATTN_NS_DKV, D = NS - 1;
 #pragma unroll
     for (int i = 0; i < D; ++i)
         if (i < ntile) stage(i, smem + i * DKV_STAGE);
-    // one 32-query tile out of ring stage S (compile-time)
-    auto query_tile = [&](int t, auto stage_c) {
-        constexpr int S = decltype(stage_c)::value;
-        constexpr int QB = S * DKV_STAGE, GB = QB + QT_TILE;
-        if (t + D - 1 < ntile) {       // per-wave DMA instructions of a stage: Q 1 + dO 1, wave 0 also the lse / delta row
-            if (wave == 0) vm_wait<3 * (D - 1)>();
-            else vm_wait<2 * (D - 1)>();
-        } else {
-            vm_wait<0>();
-        }
-        block_sync();
-#if !TV_ATTN_DMA_LATE
-        if (!(TV_ATTN_ABL & 8) && t + D < ntile) stage(t + D, smem + ((S + D) % NS) * DKV_STAGE);
-#endif
+    // 32-query tile U of ring stage S (both compile-time)
+    auto query_tile = [&](int t, auto stage_c, auto sub_c) {
+        constexpr int S = decltype(stage_c)::value, U = decltype(sub_c)::value;
+        constexpr int QB = S * DKV_STAGE + U * 32 * 128, GB = QB + QT_TILE;
+        constexpr int STB = S * DKV_STAGE + 2 * QT_TILE + U * 256;   // the tile's lse / delta rows
         f32x16 s, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;   // (inline-constant accumulator start: see attn_bwd_dq_kernel)
         f32x4 nl[4], nd[4];                        // accumulator rows (queries) 8g+4h+{0..3}
-        nl[0] = *(const f32x4*)(abs_st + QB + 0);
-        nl[1] = *(const f32x4*)(abs_st + QB + 32);
-        nl[2] = *(const f32x4*)(abs_st + QB + 64);
-        nl[3] = *(const f32x4*)(abs_st + QB + 96);
-        nd[0] = *(const f32x4*)(abs_st + QB + 128 + 0);
-        nd[1] = *(const f32x4*)(abs_st + QB + 128 + 32);
-        nd[2] = *(const f32x4*)(abs_st + QB + 128 + 64);
-        nd[3] = *(const f32x4*)(abs_st + QB + 128 + 96);
+        nl[0] = *(const f32x4*)(abs_st + STB + 0);
+        nl[1] = *(const f32x4*)(abs_st + STB + 32);
+        nl[2] = *(const f32x4*)(abs_st + STB + 64);
+        nl[3] = *(const f32x4*)(abs_st + STB + 96);
+        nd[0] = *(const f32x4*)(abs_st + STB + 128 + 0);
+        nd[1] = *(const f32x4*)(abs_st + STB + 128 + 32);
+        nd[2] = *(const f32x4*)(abs_st + STB + 128 + 64);
+        nd[3] = *(const f32x4*)(abs_st + STB + 128 + 96);
 #if TV_ATTN_DKV_ACCINIT
         // the query is on the accumulator ROW here: -delta of rows 8g+4h+{0..3} is one broadcast 16-byte LDS read per g and
         // IS dP's initial accumulator as it arrives (no 16 v_add_f32 per tile, no second copy in registers)
@@ -1071,9 +1066,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         s = mfma32(read_rows_imm<QB>(abs_r[3]), kf[3], s);
         dp = mfma32(read_rows_imm<GB>(abs_r[3]), vf[3], dp);
 #if TV_ATTN_DMA_LATE
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(TV_ATTN_ABL & 8) && t + D < ntile) stage(t + D, smem + ((S + D) % NS) * DKV_STAGE);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (U == 0) {   // the next stage's pieces in the shadow of the stage's first S / dP MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(TV_ATTN_ABL & 8) && t + D < ntile) stage(t + D, smem + ((S + D) % NS) * DKV_STAGE);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #endif
         bf16x8 gfr[2][2], qfr[2][2];   // dO^T and Q^T fragments (transposed asm reads)
 #pragma unroll
@@ -1106,7 +1103,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
             }
         }
     };
-    ring_for<NS>(ntile, query_tile);
+    // a ring stage: one counted wait and one barrier, then its DKV_QS tiles
+    auto query_stage = [&](int t, auto stage_c) {
+        constexpr int S = decltype(stage_c)::value;
+        if (t + D - 1 < ntile) {       // per-wave DMA instructions of a stage: Q and dO DKV_QS each, waves < DKV_QS a statistics row too
+            if (wave < DKV_QS) vm_wait<(2 * DKV_QS + 1) * (D - 1)>();
+            else vm_wait<2 * DKV_QS * (D - 1)>();
+        } else {
+            vm_wait<0>();
+        }
+        block_sync();
+#if !TV_ATTN_DMA_LATE
+        if (!(TV_ATTN_ABL & 8) && t + D < ntile) stage(t + D, smem + ((S + D) % NS) * DKV_STAGE);
+#endif
+        query_tile(t, stage_c, ic<0>{});
+        if constexpr (DKV_QS > 1) {
+            if ((t * DKV_QS + 1) * 32 < p.N) query_tile(t, stage_c, ic<1>{});
+        }
+    };
+    ring_for<NS>(ntile, query_stage);
     if (k_ok) {
         bf16* krow = p.out + ((size_t)b * p.N + ki) * ld + C + head * 64;
         bf16* vrow = krow + C;
