@@ -696,6 +696,41 @@ def test_attention_fwd_bwd(B, H, W, heads, rope):
         assert rel(g[..., i * C:(i + 1) * C], x.grad[..., i * C:(i + 1) * C]) < 2e-2, f"d{nm}"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [512, 2304])
+def test_attention_deferred_rescale_is_exercised_by_spiked_keys(N):
+    """The forward kernels rescale their running sums only when a row's maximum grows by more than 2^8 in the exponent
+    (attention.hip, TV_ATTN_LAZY).  Bounded random scores never take that branch after the first key block, so this input
+    forces it: scores of a wide range, and a few keys late in the sequence aligned with a few queries so that those rows'
+    maxima jump by hundreds of exponent units at chosen key blocks (and stay put for the others in the same wave).  Output
+    and all three gradients against an fp32 reference; both kernels (32 and 64 queries per wave)."""
+    from transvae.hip import ops
+    heads, B = 2, 1
+    C = heads * 64
+    g = torch.Generator().manual_seed(23)
+    q = torch.randn(B, N, heads, 64, generator=g) * 2.0
+    k = torch.randn(B, N, heads, 64, generator=g) * 2.0
+    v = torch.randn(B, N, heads, 64, generator=g)
+    for (kj, qi, gain) in ((N // 2 + 3, 5, 6.0), (N - 70, 40, 9.0), (N - 1, 130, 12.0), (200, 131, 4.0)):
+        k[0, kj] = q[0, qi] * gain / 2.0            # score ~ gain * |q|^2 / 8 / 2: far above the rest of the row
+    qkv = r16(torch.cat([q.reshape(B, N, C), k.reshape(B, N, C), v.reshape(B, N, C)], dim=-1))
+    go = r16(torch.randn(B, N, C, generator=g))
+    x = qkv.clone().requires_grad_(True)
+    qq, kk, vv = [t.view(B, N, heads, 64).transpose(1, 2) for t in x.split(C, dim=-1)]
+    sc = (qq @ kk.transpose(-1, -2)) * 0.125
+    assert float(sc.detach().max()) > 60.0 and float(sc.detach().std()) > 3.0     # the range that makes the branch matter
+    oref = (torch.softmax(sc, -1) @ vv).transpose(1, 2).reshape(B, N, C)
+    oref.backward(go)
+    xd = qkv.to(dev(), BF).requires_grad_(True)
+    o = ops.attention(xd.clone(), None, heads, 0.125)
+    assert torch.isfinite(o.float()).all()
+    assert rel(o, oref) < 1e-2, rel(o, oref)
+    o.backward(go.to(dev(), BF))
+    gq = xd.grad.cpu().float()
+    for i, nm in enumerate("qkv"):
+        assert rel(gq[..., i * C:(i + 1) * C], x.grad[..., i * C:(i + 1) * C]) < 2e-2, f"d{nm}"
+
+
 # ---- register epilogues (igemm_common.h: EF_*) against the generic LDS loop ---------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(0, 0, 0, 0), (256, 256, 0, 0), (256, 192, 0, 0), (128, 128, 0, 0)])
