@@ -36,6 +36,11 @@ struct IgemmArgs {
     const float* rope; // QKV projection: RoPE table [tokens][4][32] applied to output columns < rope_cols (q and k thirds)
     int rope_tokens, rope_cols;
     int hw_shift, w_shift;  // log2 of h_out*w_out / w_out when both are powers of two, else -1
+    // shuffled stores (store_shuffle 1 / 2): x / d for d = h_out*w_out, w_out, N/4 as  umulhi(x, m) >> s  (x < 2^31; m = 0: d = 1).
+    // The LDS epilogue split every 16-byte chunk's (pixel, channel) with three integer divisions (~40 instructions each):
+    // the pixel-shuffle / polyphase / parity layers spent up to 45 % of their time there (profiles/r03_kernel_experiments.txt item 19)
+    unsigned dv_hw_m, dv_w_m, dv_cq_m;
+    int dv_hw_s, dv_w_s, dv_cq_s;
     unsigned x_bytes, w_bytes;  // MODE 2: extents of the two buffers (< 2 GiB)
 };
 
@@ -124,6 +129,10 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+__device__ __forceinline__ int fast_div(int x, unsigned m, int sh) {   // x / d for 0 <= x < 2^31 (host: igemm_fast_div)
+    return m ? (int)(__umulhi((unsigned)x, m) >> sh) : x;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -210,7 +219,10 @@ __device__ __forceinline__ void load_bias(const IgemmArgs& p, int lane, int nw0,
 // 1385 TFLOP/s); results bit-identical (same fp32 arithmetic, one rounding).
 enum { EF_GENERIC = 0, EF_PLAIN = 1, EF_GELU_D = 2, EF_SILU_D = 3, EF_GELU = 4, EF_SILU = 5, EF_RES = 6, EF_DERIV = 7,
        EF_RES_DERIV = 8,   // (acc + residual) * saved derivative: the data gradient that joins two branches
-       EF_ROPE = 9 };      // QKV projection with the RoPE rotation of its q / k columns
+       EF_ROPE = 9,        // QKV projection with the RoPE rotation of its q / k columns
+       // register forms with a SHUFFLED store (round 3): pixel-shuffle (store_shuffle 1: DC paths, parity data gradient of the
+       // stride-2 convolutions) and the phase-shuffled store of the polyphase upsampling convolution (store_shuffle 2)
+       EF_PLAIN_S1 = 10, EF_RES_S1 = 11, EF_DERIV_S1 = 12, EF_SILU_D_S2 = 13, EF_PLAIN_S2 = 14 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void epi_pair_exchange(bf16x8& a, bf16x8& b) {   // an involution: lanes fi < 8 keep a, lanes fi >= 8 keep b
@@ -310,7 +322,10 @@ __device__ __forceinline__ bf16x8 epi_math(float (&v)[8], const bf16x8& ld, cons
     return z;
 }
 
-template <int WTM, int WTN, int FORM, class RowMap>
+// SH = store_shuffle of the launch (compile time): where element (GEMM row m, GEMM column nx .. nx+7) lives in the output
+// tensor -- the address arithmetic of the LDS loop, per 16-byte piece of a line (a 64-channel pair of blocks never straddles
+// a phase: the host sends only N/4 % 64 == 0 here).  Residual / saved tensors have the output's layout: same offsets.
+template <int WTM, int WTN, int FORM, int SH = 0, class RowMap>
 __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 (&acc)[WTM / 16][WTN / 16], const f32x4 (&bv)[WTN / 16],
                                                 int lane, int nw0, RowMap m_of_row) {
     constexpr int MF = WTM / 16, NF = WTN / 16, NC = NF / 2;
@@ -326,6 +341,30 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
     const bf16* __restrict__ lsrc2 = p.aux;
     const int lidx = epi_line_index(lane), hidx = epi_half_index(lane);
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto out_off = [&](int m, int nx, bool& ok) -> size_t {
+        ok = m < p.M && nx < p.N;
+        if constexpr (SH == 0) {
+            return ok ? (size_t)m * p.ldo + nx : 0;
+        } else {
+            if (!ok) return 0;
+            const int hw = p.h_out * p.w_out;
+            const int sb = fast_div(m, p.dv_hw_m, p.dv_hw_s);
+            const int rr = m - sb * hw;
+            const int sy = fast_div(rr, p.dv_w_m, p.dv_w_s), sx = rr - sy * p.w_out;
+            const int cq = p.N >> 2;
+            const int qs = fast_div(nx, p.dv_cq_m, p.dv_cq_s);
+            const int c = nx - qs * cq;
+            if constexpr (SH == 1) {
+                const size_t pix = ((size_t)sb * (2 * p.h_out) + 2 * sy + (qs >> 1)) * (2 * p.w_out) + 2 * sx + (qs & 1);
+                return pix * p.ldo + c;
+            } else {   // polyphase: phase (py, px) of cell (sy, sx) is pixel (2 sy - py, 2 sx - px) of the [2(H-1), 2(W-1)] output grid
+                const int Y = 2 * sy - (qs >> 1), X = 2 * sx - (qs & 1);
+                const int H2 = 2 * (p.h_out - 1), W2 = 2 * (p.w_out - 1);
+                if ((unsigned)Y >= (unsigned)H2 || (unsigned)X >= (unsigned)W2) { ok = false; return 0; }
+                return (((size_t)sb * H2 + Y) * W2 + X) * p.ldo + c;
+            }
+        }
+    };
     auto chunk_values = [&](int i, int c, float (&v)[8]) {
         const f32x4 lo = acc[i][2 * c] + bv[2 * c], hi = acc[i][2 * c + 1] + bv[2 * c + 1];
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
@@ -349,10 +388,8 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
                     const int nx = nw0 + (P0 + 2 * u) * 32 + (lane & 7) * 8;   //          my channels
-                    k1[ii][u] = m1 < p.M && nx < p.N;
-                    k2[ii][u] = m2 < p.M && nx < p.N;
-                    o1[ii][u] = k1[ii][u] ? (size_t)m1 * p.ldo + nx : 0;
-                    o2[ii][u] = k2[ii][u] ? (size_t)m2 * p.ldo + nx : 0;
+                    o1[ii][u] = out_off(m1, nx, k1[ii][u]);
+                    o2[ii][u] = out_off(m2, nx, k2[ii][u]);
                     if constexpr (LOADS) {
                         la[ii][u] = k1[ii][u] ? *(const bf16x8*)(lsrc + o1[ii][u]) : zero8;
                         lb[ii][u] = k2[ii][u] ? *(const bf16x8*)(lsrc + o2[ii][u]) : zero8;
@@ -365,8 +402,7 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
                 if constexpr (SINGLE) {
                     const int ms = m_of_row((i0 + ii) * 16 + (lane >> 2));
                     const int nx = nw0 + S0 * 32 + (lane & 3) * 8;
-                    ks[ii] = ms < p.M && nx < p.N;
-                    os[ii] = ks[ii] ? (size_t)ms * p.ldo + nx : 0;
+                    os[ii] = out_off(ms, nx, ks[ii]);
                     if constexpr (LOADS) ls[ii] = ks[ii] ? *(const bf16x8*)(lsrc + os[ii]) : zero8;
                     if constexpr (LOADS2) ls2[ii] = ks[ii] ? *(const bf16x8*)(lsrc2 + os[ii]) : zero8;
                 }
@@ -523,20 +559,20 @@ __device__ __forceinline__ void epilogue_lds(const IgemmArgs& p, const f32x4 (&a
             if (m >= p.M || n >= p.N) continue;
             size_t off;
             if (p.shuffle == 2) {   // polyphase upsampling conv: grid (H+1) x (W+1), phase (py, px) of cell (sy, sx) is pixel
-                const int sb = m / hw;                      //   (2*sy - py, 2*sx - px) of the [2H, 2W] output; cells on the rim
-                const int rr = m - sb * hw;                 //   have phases that fall outside
-                const int sy = rr / p.w_out, sx = rr - sy * p.w_out;
-                const int qs = n / cq;
+                const int sb = fast_div(m, p.dv_hw_m, p.dv_hw_s);   //   (2*sy - py, 2*sx - px) of the [2H, 2W] output; cells on the rim
+                const int rr = m - sb * hw;                         //   have phases that fall outside
+                const int sy = fast_div(rr, p.dv_w_m, p.dv_w_s), sx = rr - sy * p.w_out;
+                const int qs = fast_div(n, p.dv_cq_m, p.dv_cq_s);
                 const int c = n - qs * cq;
                 const int Y = 2 * sy - (qs >> 1), X = 2 * sx - (qs & 1);
                 const int H2 = 2 * (p.h_out - 1), W2 = 2 * (p.w_out - 1);
                 if ((unsigned)Y >= (unsigned)H2 || (unsigned)X >= (unsigned)W2) continue;
                 off = (((size_t)sb * H2 + Y) * W2 + X) * p.ldo + c;
             } else if (p.shuffle) {
-                const int sb = m / hw;
+                const int sb = fast_div(m, p.dv_hw_m, p.dv_hw_s);
                 const int rr = m - sb * hw;
-                const int sy = rr / p.w_out, sx = rr - sy * p.w_out;
-                const int qs = n / cq;
+                const int sy = fast_div(rr, p.dv_w_m, p.dv_w_s), sx = rr - sy * p.w_out;
+                const int qs = fast_div(n, p.dv_cq_m, p.dv_cq_s);
                 const int c = n - qs * cq;
                 const size_t pix = ((size_t)sb * (2 * p.h_out) + 2 * sy + (qs >> 1)) * (2 * p.w_out) + 2 * sx + (qs & 1);
                 off = pix * p.ldo + c;
@@ -620,6 +656,11 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
                 case EF_SILU: epilogue_direct<WTM, WTN, EF_SILU>(p, acc, bv, lane, nw0, m_of_row); return;
                 case EF_RES_DERIV: epilogue_direct<WTM, WTN, EF_RES_DERIV>(p, acc, bv, lane, nw0, m_of_row); return;
                 case EF_ROPE: epilogue_direct<WTM, WTN, EF_ROPE>(p, acc, bv, lane, nw0, m_of_row); return;
+                case EF_PLAIN_S1: epilogue_direct<WTM, WTN, EF_PLAIN, 1>(p, acc, bv, lane, nw0, m_of_row); return;
+                case EF_RES_S1: epilogue_direct<WTM, WTN, EF_RES, 1>(p, acc, bv, lane, nw0, m_of_row); return;
+                case EF_DERIV_S1: epilogue_direct<WTM, WTN, EF_DERIV, 1>(p, acc, bv, lane, nw0, m_of_row); return;
+                case EF_SILU_D_S2: epilogue_direct<WTM, WTN, EF_SILU_D, 2>(p, acc, bv, lane, nw0, m_of_row); return;
+                case EF_PLAIN_S2: epilogue_direct<WTM, WTN, EF_PLAIN, 2>(p, acc, bv, lane, nw0, m_of_row); return;
                 default: break;
             }
         }

@@ -916,7 +916,18 @@ bool g_use_halo = true;  // 3x3 stride-1 convolutions through conv3x3_halo_kerne
 
 // register form of an EPI 0 launch (see epilogue<>): the common elementwise combinations; everything else -> LDS loop
 int epilogue_form(const IgemmArgs& a) {
-    if (!g_epi_modes || a.shuffle) return EF_GENERIC;
+    if (!g_epi_modes) return EF_GENERIC;
+    if (a.shuffle) {   // shuffled stores: the forms the model uses (a 64-channel pair of blocks must stay inside one phase)
+        if (a.rope || ((a.N >> 2) % 64) != 0 || (a.N & 3)) return EF_GENERIC;
+        if (a.shuffle == 1) {
+            if (a.aux) return (a.aux_act == TV_ACT_DERIV && !a.res && !a.pre && a.act == TV_ACT_NONE) ? EF_DERIV_S1 : EF_GENERIC;
+            if (a.pre || a.act != TV_ACT_NONE) return EF_GENERIC;
+            return a.res ? EF_RES_S1 : EF_PLAIN_S1;
+        }
+        if (a.aux || a.res) return EF_GENERIC;
+        if (a.pre) return (a.pre_deriv && a.act == TV_ACT_SILU) ? EF_SILU_D_S2 : EF_GENERIC;
+        return a.act == TV_ACT_NONE ? EF_PLAIN_S2 : EF_GENERIC;
+    }
     if (a.rope) return (!a.aux && !a.res && !a.pre && a.act == TV_ACT_NONE && a.rope_cols % 32 == 0) ? EF_ROPE : EF_GENERIC;
     if (a.aux) return (a.res && a.aux_act == TV_ACT_DERIV && !a.pre && a.act == TV_ACT_NONE) ? EF_RES_DERIV : EF_GENERIC;
     if (a.res) return EF_GENERIC;
@@ -1188,6 +1199,18 @@ static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, co
         a.w_shift = lg(d->w_out);
         a.hw_shift = lg(d->h_out * d->w_out);
         if (a.hw_shift < 0 || a.w_shift < 0) a.hw_shift = a.w_shift = -1;
+    }
+    {   // x / d as umulhi(x, m) >> s for 0 <= x < 2^31 (round-up method with 31 + ceil(log2 d) bits: exact on that range)
+        auto fd = [](int d, unsigned& m, int& sh) {
+            if (d <= 1) { m = 0; sh = 0; return; }
+            int L = 0;
+            while ((1ll << L) < d) ++L;
+            m = (unsigned)(((1ull << (31 + L)) + (unsigned long long)d - 1) / (unsigned long long)d);
+            sh = L - 1;
+        };
+        fd(d->h_out * d->w_out, a.dv_hw_m, a.dv_hw_s);
+        fd(d->w_out, a.dv_w_m, a.dv_w_s);
+        fd(a.N >> 2, a.dv_cq_m, a.dv_cq_s);
     }
     {   // buffer-descriptor extents (0 = too large for 32-bit offsets -> global-address DMA)
         const long long xb = ((long long)d->batch * d->h_in * d->w_in - 1) * d->ldx * 2 + (long long)d->c_in * 2;

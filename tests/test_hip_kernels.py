@@ -877,3 +877,57 @@ def test_eight_phase_loop_is_bit_identical_to_the_plain_loop(M, K, N, bn):
         for k in ref:
             assert torch.isfinite(r[k].float()).all(), k
             assert torch.equal(r[k], ref[k]), (k, float((r[k].float() - ref[k].float()).abs().max()))
+
+
+# ---- register epilogue forms with shuffled stores (pixel-shuffle / polyphase) against the generic LDS loop -----------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H", [(4, 32), (3, 24), (8, 64)])
+def test_shuffled_store_register_forms_are_bit_identical_to_the_lds_loop(B, H):
+    """DC paths (1x1 + pixel-shuffle store, the data gradient of the 2x2-stride-2 gather), the parity data gradient of a
+    stride-2 3x3 convolution (x saved derivative) and the polyphase upsampling convolution (SiLU + saved derivative, rim
+    phases clipped): the register forms compute each 16-byte piece's address like the LDS loop does and must give its bits
+    -- power-of-two and other grids, full and ragged row tiles."""
+    from transvae.hip import _lib as L, ops
+    lib = L.load()
+    g = torch.Generator(device=dev()).manual_seed(29)
+    bf = torch.bfloat16
+    C = 192
+
+    def rnd(*shape):
+        return torch.randn(*shape, device=dev(), generator=g)
+    x = rnd(B, H, H, C).to(bf)
+    xl = rnd(B, H // 2, H // 2, C).to(bf)                    # low-resolution input of the up path
+    w_shuf = rnd(4 * C, 1, 1, C) * C ** -0.5                 # 1x1 -> 4C, stored pixel-shuffled to [B, H, H, C]
+    b_shuf = rnd(4 * C) * 0.1
+    res_hi = rnd(B, H, H, C).to(bf)
+    w_un = rnd(C, 2, 2, C) * (4 * C) ** -0.5                 # 2x2 / stride-2 gather conv  [B,H,H,C] -> [B,H/2,H/2,C]
+    w_s2 = rnd(C, 3, 3, C) * (9 * C) ** -0.5
+    w_up = rnd(C, 3, 3, C) * (9 * C) ** -0.5
+    b_up = rnd(C) * 0.1
+    gz_lo = rnd(B, H // 2, H // 2, C).to(bf)
+    der_hi = torch.rand(B, H, H, C, device=dev(), generator=g).to(bf)
+
+    def cases():
+        out = {}
+        out["shuf"] = ops.conv_forward(xl, w_shuf, b_shuf, None, "shuf", L.ACT_NONE, False)[0]
+        out["shuf+res"] = ops.conv_forward(xl, w_shuf, b_shuf, res_hi, "shuf", L.ACT_NONE, False)[0]
+        g_un = ops._Geo("unshuf", x, w_un)
+        out["unshuf dgrad"] = ops.conv_dgrad(g_un, w_un, gz_lo, x.shape)
+        out["unshuf dgrad+res"] = ops.conv_dgrad(g_un, w_un, gz_lo, x.shape, residual=res_hi)
+        g_s2 = ops._Geo("c3s2", x, w_s2)
+        out["c3s2 dgrad*deriv"] = ops.conv_dgrad(g_s2, w_s2, gz_lo, x.shape, aux=der_hi, aux_act=L.ACT_DERIV)
+        out["c3s2 dgrad"] = ops.conv_dgrad(g_s2, w_s2, gz_lo, x.shape)
+        y, d = ops.conv_forward(xl, w_up, b_up, None, "c3up", L.ACT_SILU, "deriv")[:2]
+        out["c3up silu+deriv"], out["c3up silu+deriv:saved"] = y, d
+        out["c3up"] = ops.conv_forward(xl, w_up, b_up, None, "c3up", L.ACT_NONE, False)[0]
+        return out
+    try:
+        lib.tv_set_igemm_epilogue(1)
+        reg = cases()
+        lib.tv_set_igemm_epilogue(0)
+        lds = cases()
+    finally:
+        lib.tv_set_igemm_epilogue(1)
+    for k in reg:
+        assert torch.isfinite(reg[k].float()).all(), k
+        assert torch.equal(reg[k], lds[k]), (k, float((reg[k].float() - lds[k].float()).abs().max()))
