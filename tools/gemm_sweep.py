@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--wblocks", type=int, default=0, help="wgrad split-K block target (0 = heuristic)")
     ap.add_argument("--wwaves", type=int, default=0, help="wgrad waves per block (0 = heuristic, 4)")
     args = ap.parse_args()
+    if os.environ.get("TV_SWEEP_PERSIST"):   # tv_set_igemm_persist hook (A/B of the loop variants)
+        from transvae.hip import _lib as _L
+        _L.load().tv_set_igemm_persist(int(os.environ["TV_SWEEP_PERSIST"]))
     if args.cfg:
         from transvae.hip import _lib
         _lib.load().tv_set_igemm_config(*[int(v) for v in args.cfg.split(",")])
