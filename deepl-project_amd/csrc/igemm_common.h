@@ -41,6 +41,8 @@ struct IgemmArgs {
     // the pixel-shuffle / polyphase / parity layers spent up to 45 % of their time there (profiles/r03_kernel_experiments.txt item 19)
     unsigned dv_hw_m, dv_w_m, dv_cq_m;
     int dv_hw_s, dv_w_s, dv_cq_s;
+    unsigned out_bytes;   // extent of out (and of pre / res / aux: same shape) when below 2 GiB, else 0: the register epilogues
+                          // address them through buffer descriptors with 32-bit offsets
     unsigned x_bytes, w_bytes;  // MODE 2: extents of the two buffers (< 2 GiB)
 };
 
@@ -325,6 +327,30 @@ __device__ __forceinline__ bf16x8 epi_math(float (&v)[8], const bf16x8& ld, cons
 // SH = store_shuffle of the launch (compile time): where element (GEMM row m, GEMM column nx .. nx+7) lives in the output
 // tensor -- the address arithmetic of the LDS loop, per 16-byte piece of a line (a 64-channel pair of blocks never straddles
 // a phase: the host sends only N/4 % 64 == 0 here).  Residual / saved tensors have the output's layout: same offsets.
+// TV_EPI_BUF (round 3): every load / store of the register epilogue goes through a buffer descriptor with a 32-bit byte offset
+// per lane, masked pieces as OUT-OF-RANGE offsets (a store is dropped, a load returns zeros).  The pointer form predicated each
+// access (`if (ok) store`): one basic block and an s_cbranch_execz per store, 64-bit address arithmetic per piece -- the rows
+// of a tile went out strictly one after the other, every cross-lane transposition exposed in front of its store.  Without
+// branches the body is one block: the scheduler runs the transpositions of later rows under earlier stores.  The host sends
+// only tensors below 2 GiB here (out_bytes; larger ones keep the LDS loop).
+#ifndef TV_EPI_BUF
+#define TV_EPI_BUF 1
+#endif
+typedef unsigned int epi_u32x4 __attribute__((__vector_size__(16)));
+__device__ __forceinline__ bf16x8 epi_bload(const void* base, unsigned bytes, int off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const epi_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000), off, 0, 0);
+    return __builtin_bit_cast(bf16x8, v);
+#else
+    return bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+}
+__device__ __forceinline__ void epi_bstore(void* base, unsigned bytes, int off, const bf16x8& z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(epi_u32x4, z), __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000), off, 0, 0);
+#endif
+}
+
 template <int WTM, int WTN, int FORM, int SH = 0, class RowMap>
 __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 (&acc)[WTM / 16][WTN / 16], const f32x4 (&bv)[WTN / 16],
                                                 int lane, int nw0, RowMap m_of_row) {
@@ -341,12 +367,14 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
     const bf16* __restrict__ lsrc2 = p.aux;
     const int lidx = epi_line_index(lane), hidx = epi_half_index(lane);
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto out_off = [&](int m, int nx, bool& ok) -> size_t {
-        ok = m < p.M && nx < p.N;
+    // BYTE offset of element (GEMM row m, GEMM column nx) in the output tensor (residual / saved tensors share its layout), or
+    // OOB_OFFSET for a masked piece
+    auto out_off = [&](int m, int nx) -> int {
+        const bool ok = m < p.M && nx < p.N;
         if constexpr (SH == 0) {
-            return ok ? (size_t)m * p.ldo + nx : 0;
+            return ok ? (m * p.ldo + nx) * 2 : OOB_OFFSET;
         } else {
-            if (!ok) return 0;
+            if (!ok) return OOB_OFFSET;
             const int hw = p.h_out * p.w_out;
             const int sb = fast_div(m, p.dv_hw_m, p.dv_hw_s);
             const int rr = m - sb * hw;
@@ -355,15 +383,30 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
             const int qs = fast_div(nx, p.dv_cq_m, p.dv_cq_s);
             const int c = nx - qs * cq;
             if constexpr (SH == 1) {
-                const size_t pix = ((size_t)sb * (2 * p.h_out) + 2 * sy + (qs >> 1)) * (2 * p.w_out) + 2 * sx + (qs & 1);
-                return pix * p.ldo + c;
+                const int pix = (sb * (2 * p.h_out) + 2 * sy + (qs >> 1)) * (2 * p.w_out) + 2 * sx + (qs & 1);
+                return (pix * p.ldo + c) * 2;
             } else {   // polyphase: phase (py, px) of cell (sy, sx) is pixel (2 sy - py, 2 sx - px) of the [2(H-1), 2(W-1)] output grid
                 const int Y = 2 * sy - (qs >> 1), X = 2 * sx - (qs & 1);
                 const int H2 = 2 * (p.h_out - 1), W2 = 2 * (p.w_out - 1);
-                if ((unsigned)Y >= (unsigned)H2 || (unsigned)X >= (unsigned)W2) { ok = false; return 0; }
-                return (((size_t)sb * H2 + Y) * W2 + X) * p.ldo + c;
+                if ((unsigned)Y >= (unsigned)H2 || (unsigned)X >= (unsigned)W2) return OOB_OFFSET;
+                return (((sb * H2 + Y) * W2 + X) * p.ldo + c) * 2;
             }
         }
+    };
+    // (the pointer form of an access, kept behind TV_EPI_BUF = 0 for A/B: same offsets, predicated)
+    auto ld = [&](const bf16* base, int off) -> bf16x8 {
+#if TV_EPI_BUF
+        return epi_bload(base, p.out_bytes, off);
+#else
+        return off != OOB_OFFSET ? *(const bf16x8*)((const char*)base + (unsigned)off) : zero8;
+#endif
+    };
+    auto st = [&](bf16* base, int off, const bf16x8& z) {
+#if TV_EPI_BUF
+        epi_bstore(base, p.out_bytes, off, z);
+#else
+        if (off != OOB_OFFSET) *(bf16x8*)((char*)base + (unsigned)off) = z;
+#endif
     };
     auto chunk_values = [&](int i, int c, float (&v)[8]) {
         const f32x4 lo = acc[i][2 * c] + bv[2 * c], hi = acc[i][2 * c + 1] + bv[2 * c + 1];
@@ -377,8 +420,7 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
         constexpr bool SINGLE = P0 + 2 * NP < NC || ODD;
         static_for<0, MF / IB>([&](auto b_c) {
             constexpr int i0 = decltype(b_c)::value * IB;
-            size_t o1[IB][NP > 0 ? NP : 1], o2[IB][NP > 0 ? NP : 1], os[IB];
-            bool k1[IB][NP > 0 ? NP : 1], k2[IB][NP > 0 ? NP : 1], ks[IB];
+            int o1[IB][NP > 0 ? NP : 1], o2[IB][NP > 0 ? NP : 1], os[IB];
             [[maybe_unused]] bf16x8 la[IB][NP > 0 ? NP : 1], lb[IB][NP > 0 ? NP : 1], ls[IB];
             [[maybe_unused]] bf16x8 la2[IB][NP > 0 ? NP : 1], lb2[IB][NP > 0 ? NP : 1], ls2[IB];
 #pragma unroll
@@ -388,23 +430,23 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
 #pragma unroll
                 for (int u = 0; u < NP; ++u) {
                     const int nx = nw0 + (P0 + 2 * u) * 32 + (lane & 7) * 8;   //          my channels
-                    o1[ii][u] = out_off(m1, nx, k1[ii][u]);
-                    o2[ii][u] = out_off(m2, nx, k2[ii][u]);
+                    o1[ii][u] = out_off(m1, nx);
+                    o2[ii][u] = out_off(m2, nx);
                     if constexpr (LOADS) {
-                        la[ii][u] = k1[ii][u] ? *(const bf16x8*)(lsrc + o1[ii][u]) : zero8;
-                        lb[ii][u] = k2[ii][u] ? *(const bf16x8*)(lsrc + o2[ii][u]) : zero8;
+                        la[ii][u] = ld(lsrc, o1[ii][u]);
+                        lb[ii][u] = ld(lsrc, o2[ii][u]);
                     }
                     if constexpr (LOADS2) {
-                        la2[ii][u] = k1[ii][u] ? *(const bf16x8*)(lsrc2 + o1[ii][u]) : zero8;
-                        lb2[ii][u] = k2[ii][u] ? *(const bf16x8*)(lsrc2 + o2[ii][u]) : zero8;
+                        la2[ii][u] = ld(lsrc2, o1[ii][u]);
+                        lb2[ii][u] = ld(lsrc2, o2[ii][u]);
                     }
                 }
                 if constexpr (SINGLE) {
                     const int ms = m_of_row((i0 + ii) * 16 + (lane >> 2));
                     const int nx = nw0 + S0 * 32 + (lane & 3) * 8;
-                    os[ii] = out_off(ms, nx, ks[ii]);
-                    if constexpr (LOADS) ls[ii] = ks[ii] ? *(const bf16x8*)(lsrc + os[ii]) : zero8;
-                    if constexpr (LOADS2) ls2[ii] = ks[ii] ? *(const bf16x8*)(lsrc2 + os[ii]) : zero8;
+                    os[ii] = out_off(ms, nx);
+                    if constexpr (LOADS) ls[ii] = ld(lsrc, os[ii]);
+                    if constexpr (LOADS2) ls2[ii] = ld(lsrc2, os[ii]);
                 }
             }
 #pragma unroll
@@ -437,16 +479,16 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
                     bf16x8 zb = epi_math<FORM>(vb, rb, rb2, db);
                     if constexpr (SAVES) {
                         epi_to_lines(da, db, lidx);
-                        if (k1[ii][u]) *(bf16x8*)(p.pre + o1[ii][u]) = da;
-                        if (k2[ii][u]) *(bf16x8*)(p.pre + o2[ii][u]) = db;
+                        st(p.pre, o1[ii][u], da);
+                        st(p.pre, o2[ii][u], db);
                     }
                     epi_to_lines(za, zb, lidx);
 #ifdef TV_ABL_NO_STORE
                     if (za[0] == (bf16)123.0f)   // (keeps the values live; practically never true)
 #endif
                     {
-                        if (k1[ii][u]) *(bf16x8*)(p.out + o1[ii][u]) = za;
-                        if (k2[ii][u]) *(bf16x8*)(p.out + o2[ii][u]) = zb;
+                        st(p.out, o1[ii][u], za);
+                        st(p.out, o2[ii][u], zb);
                     }
                 }
                 if constexpr (SINGLE) {
@@ -469,13 +511,13 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
                     bf16x8 z = epi_math<FORM>(v, r, r2, d);
                     if constexpr (SAVES) {
                         epi_to_half(d, hidx);
-                        if (ks[ii]) *(bf16x8*)(p.pre + os[ii]) = d;
+                        st(p.pre, os[ii], d);
                     }
                     epi_to_half(z, hidx);
 #ifdef TV_ABL_NO_STORE
                     if (z[0] == (bf16)123.0f)
 #endif
-                    if (ks[ii]) *(bf16x8*)(p.out + os[ii]) = z;
+                    st(p.out, os[ii], z);
                 }
             }
         });

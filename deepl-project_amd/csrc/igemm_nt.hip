@@ -34,7 +34,7 @@ bool g_epi_modes = true;   // compile-time epilogue forms (tv_set_igemm_epilogue
 // which epilogue form a call takes (see epilogue<>): 1 = residual add only, 2 = saved-derivative multiply, 0 = the rest
 int epilogue_mode(const IgemmArgs& a) {
     if (a.rope) return 0;
-    if (!g_epi_modes || a.shuffle || a.pre || ((long long)a.M * a.ldo >> 3) >= 0xffffffffll) return 0;
+    if (!g_epi_modes || a.shuffle || a.pre || a.out_bytes == 0) return 0;
     if (a.aux) return (a.aux_act == TV_ACT_DERIV && !a.res) ? 2 : 0;
     return (a.res && a.act == TV_ACT_NONE) ? 1 : 0;
 }
@@ -1217,6 +1217,11 @@ static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, co
         const long long wb = (long long)a.N * a.K * 2;
         a.x_bytes = xb < (1ll << 31) ? (unsigned)xb : 0u;
         a.w_bytes = wb < (1ll << 31) ? (unsigned)wb : 0u;
+    }
+    {   // extent of the output tensor (shuffled stores: 4 M pixels of N / 4 channels; the polyphase grid is smaller still)
+        const long long ob = d->store_shuffle ? ((4ll * M - 1) * d->ldo + (a.N >> 2)) * 2 : ((M - 1) * (long long)d->ldo + a.N) * 2;
+        a.out_bytes = ob < (1ll << 31) ? (unsigned)ob : 0u;
+        if (a.out_bytes == 0) a.form = EF_GENERIC;   // (the register forms carry 32-bit offsets; epilogue_mode() checks the same)
     }
     hipStream_t s = (hipStream_t)stream;
     const bool bk64 = (d->c_in % 64 == 0) && g_cfg_bk != 32;
