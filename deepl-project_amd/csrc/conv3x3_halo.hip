@@ -757,6 +757,11 @@ int launch_halo_impl(IgemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+#ifdef TV_EXP_GN_EPI
+extern "C" int tv_set_gn_epi_probe(void* dev_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gn_epi_buf), &dev_buf, sizeof(void*)) == hipSuccess ? 0 : 1;
+}
+#endif
 namespace tvi {
 int launch_halo(IgemmArgs& a, hipStream_t s) { return launch_halo_impl(a, s); }
 #ifdef TV_PROBE

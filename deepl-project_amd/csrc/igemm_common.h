@@ -337,6 +337,9 @@ __device__ __forceinline__ bf16x8 epi_math(float (&v)[8], const bf16x8& ld, cons
 #define TV_EPI_BUF 1
 #endif
 typedef unsigned int epi_u32x4 __attribute__((__vector_size__(16)));
+#ifdef TV_EXP_GN_EPI
+__device__ float* g_gn_epi_buf = nullptr;   // timing experiment: per-wave GroupNorm partials [block][wave][256] (tv_set_gn_epi_probe)
+#endif
 __device__ __forceinline__ bf16x8 epi_bload(const void* base, unsigned bytes, int off) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const epi_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000), off, 0, 0);
@@ -408,6 +411,17 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
         if (off != OOB_OFFSET) *(bf16x8*)((char*)base + (unsigned)off) = z;
 #endif
     };
+#ifdef TV_EXP_GN_EPI
+    constexpr bool GNX = SH == 0 && (FORM == EF_PLAIN || FORM == EF_RES) && NC == 3;
+    [[maybe_unused]] float gs1[NC][8], gs2[NC][8];
+    [[maybe_unused]] const float gn_piv = p.bias ? p.bias[0] : 0.f;   // (stand-in pivot: a per-(image, channel) value in the real thing)
+    if constexpr (GNX) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gs1[c][e] = gs2[c][e] = 0.f;
+    }
+#endif
     auto chunk_values = [&](int i, int c, float (&v)[8]) {
         const f32x4 lo = acc[i][2 * c] + bv[2 * c], hi = acc[i][2 * c + 1] + bv[2 * c + 1];
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
@@ -482,6 +496,16 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
                         st(p.pre, o1[ii][u], da);
                         st(p.pre, o2[ii][u], db);
                     }
+#ifdef TV_EXP_GN_EPI   // (timing experiment: GroupNorm statistics of the OUTPUT in the producing convolution's epilogue)
+                    if constexpr (GNX) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xa = (float)za[e] - gn_piv, xb = (float)zb[e] - gn_piv;
+                            gs1[C0][e] += xa; gs2[C0][e] = fmaf(xa, xa, gs2[C0][e]);
+                            gs1[C0 + 1][e] += xb; gs2[C0 + 1][e] = fmaf(xb, xb, gs2[C0 + 1][e]);
+                        }
+                    }
+#endif
                     epi_to_lines(za, zb, lidx);
 #ifdef TV_ABL_NO_STORE
                     if (za[0] == (bf16)123.0f)   // (keeps the values live; practically never true)
@@ -513,6 +537,15 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
                         epi_to_half(d, hidx);
                         st(p.pre, os[ii], d);
                     }
+#ifdef TV_EXP_GN_EPI
+                    if constexpr (GNX) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xa = (float)z[e] - gn_piv;
+                            gs1[S0][e] += xa; gs2[S0][e] = fmaf(xa, xa, gs2[S0][e]);
+                        }
+                    }
+#endif
                     epi_to_half(z, hidx);
 #ifdef TV_ABL_NO_STORE
                     if (z[0] == (bf16)123.0f)
@@ -528,6 +561,37 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
         if (nw0 & 32) run(std::true_type{});
         else run(std::false_type{});
     }
+#ifdef TV_EXP_GN_EPI
+    if constexpr (GNX) {
+        // the wave's 64 pixels per channel: the 16 lanes of a DPP row (same fq, pixels fi = 0..15) hold 48 partial values each
+        // (3 blocks x 8 channels x {sum, sum of squares}); reduce-scatter over the row in four halving steps (a lane keeps the
+        // half of the values its bit selects and adds the partner's copy of that half): 3 finished values per lane.
+        float v[48];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[c * 16 + e] = gs1[c][e]; v[c * 16 + 8 + e] = gs2[c][e]; }
+        int n = 48;
+#pragma unroll
+        for (int bit = 8; bit >= 1; bit >>= 1) {
+            const bool up = (lane & bit) != 0;
+            const int h = n / 2;
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                if (k < h) {
+                    const float keep = up ? v[h + k] : v[k], send = up ? v[k] : v[h + k];
+                    v[k] = keep + __shfl_xor(send, bit, 64);
+                }
+            }
+            n = h;
+        }
+        // 3 values per lane; 64 lanes x 3 = the wave's 192 statistics -> its row of the partials buffer (16-byte aligned rows)
+        if (g_gn_epi_buf) {
+            float* dst = g_gn_epi_buf + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 256 + lane * 4;
+            *(f32x4*)dst = f32x4{v[0], v[1], v[2], 0.f};
+        }
+    }
+#endif
 }
 
 template <int WTM, int WTN, int EPI, class RowMap>
