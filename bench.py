@@ -102,6 +102,34 @@ def time_dominant_kernel(mb: int, res: int, dev):
             "algorithmic_bytes_per_launch": 2 * mb * res * res * C * 2 + 9 * C * C * 2}
 
 
+def time_linear_kernel(mb: int, dev):
+    """HIP-event timing of the largest linear layer of the deepest stage (Conv-FFN proj_in, 1536 -> 6144 on 16 x 16 tokens per
+    image) through tv_igemm_nt: igemm_nt_kernel<256,256,...> on its eight-phase ping-pong loop, the second largest GEMM
+    kernel family of the step by time (profiles/r03_rocprof_kernel_stats.csv)."""
+    from transvae.hip import ops
+    from transvae.hip import _lib as L
+    M, K, N = mb * 256, 1536, 6144
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = torch.randn(N, K, device=dev) * K ** -0.5
+    b = torch.randn(N, device=dev) * 0.1
+    fn = lambda: ops.conv_forward(x, w, b, None, "linear", L.ACT_NONE, False)[0]
+    for _ in range(10):
+        fn()
+    n = 30
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flop = 2.0 * M * K * N
+    return {"bound": "mfma", "kernel": "igemm_nt_kernel<256,256,2,4,64,2,2,0; eight-phase loop> via tv_igemm_nt (linear 1536->6144, %d rows = %d images x 256 tokens)" % (M, mb),
+            "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
+            "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": (M * K + M * N + N * K) * 2}
+
+
 def time_wgrad_kernel(mb: int, res: int, dev):
     """HIP-event timing of the weight gradient (+ bias gradient) of the same stage-0 ResBlock convolution (tv_wgrad_tn ->
     wgrad_kx3_kernel): the largest weight-gradient kernel of the step (profiles/r03_rocprof_kernel_stats.csv)."""
@@ -209,7 +237,7 @@ def main():
     if args.kernel_only:
         torch.cuda.set_device(0)
         r = time_dominant_kernel(args.micro_batch, args.res, torch.device("cuda", 0))
-        r["also"] = [time_wgrad_kernel(args.micro_batch, args.res, torch.device("cuda", 0))]
+        r["also"] = [time_wgrad_kernel(args.micro_batch, args.res, torch.device("cuda", 0)), time_linear_kernel(args.micro_batch, torch.device("cuda", 0))]
         print(json.dumps(r), flush=True)
         return
 
@@ -357,7 +385,7 @@ def main():
         out["roofline"] = time_dominant_kernel(min(args.micro_batch, count), 256, dev)
         # the dominant kernel BY TIME is the 3x3 convolution above (profiles/r03_rocprof_kernel_stats.csv: 15.5 % of the step);
         # the largest weight-gradient kernel (9 %) is reported beside it
-        out["roofline"]["also"] = [time_wgrad_kernel(min(args.micro_batch, count), 256, dev)]
+        out["roofline"]["also"] = [time_wgrad_kernel(min(args.micro_batch, count), 256, dev), time_linear_kernel(min(args.micro_batch, count), dev)]
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle, 1 image) ...")
             del model, ddp, opt
