@@ -62,6 +62,19 @@ __device__ __forceinline__ float fexp2(float x) { return x; }
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #endif
 
+// output rows (o, dq, dk, dv): non-temporal stores measured 0.7 % SLOWER in the bench (the consumer GEMM finds a small o / dqkv in the
+// Infinity Cache with the default policy; item 23) -- off, kept for A/B
+#ifndef TV_ATTN_NT_STORE
+#define TV_ATTN_NT_STORE 0
+#endif
+__device__ __forceinline__ void attn_store4(bf16* ptr, const bf16x4& v) {
+#if TV_ATTN_NT_STORE
+    __builtin_nontemporal_store(v, (bf16x4*)ptr);
+#else
+    *(bf16x4*)ptr = v;
+#endif
+}
+
 // ---- ring of K / V (Q / dO) stages -------------------------------------------------------------------------------
 // Round 3: the loops staged tile t+1 while computing tile t and opened every tile with `vmcnt(0)` + barrier: one tile of
 // matrix work (512 - 1024 cycles per wave) is about the latency of an LDS-DMA piece under load, and 0.24-0.28 of the
@@ -547,7 +560,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             for (int g = 0; g < 4; ++g) {
                 bf16x4 v = {(bf16)(ot[db][4 * g] * inv), (bf16)(ot[db][4 * g + 1] * inv), (bf16)(ot[db][4 * g + 2] * inv),
                             (bf16)(ot[db][4 * g + 3] * inv)};
-                *(bf16x4*)(orow + db * 32 + 8 * g + 4 * h) = v;
+                attn_store4(orow + db * 32 + 8 * g + 4 * h, v);
             }
         if (h == 0) p.lse[((size_t)b * p.heads + head) * p.N + qi] = (m * c2 + __log2f(l)) * 0.6931471805599453f;
     }
@@ -742,7 +755,7 @@ __global__ __launch_bounds__(256, TV_ATTN_FWD64_OCC) void attn_fwd64_kernel(cons
                 for (int g = 0; g < 4; ++g) {
                     bf16x4 v = {(bf16)(ot[u][db][4 * g] * inv), (bf16)(ot[u][db][4 * g + 1] * inv), (bf16)(ot[u][db][4 * g + 2] * inv),
                                 (bf16)(ot[u][db][4 * g + 3] * inv)};
-                    *(bf16x4*)(orow + db * 32 + 8 * g + 4 * h) = v;
+                    attn_store4(orow + db * 32 + 8 * g + 4 * h, v);
                 }
             if (h == 0) p.lse[((size_t)b * p.heads + head) * p.N + qi[u]] = (m[u] * c2 + __log2f(lt)) * 0.6931471805599453f;
         }
@@ -947,7 +960,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
                 float f[4] = {dqt[db][4 * g] * p.scale, dqt[db][4 * g + 1] * p.scale, dqt[db][4 * g + 2] * p.scale, dqt[db][4 * g + 3] * p.scale};
                 if (p.rope) rope_adjoint4(f, p.rope + (size_t)qi * 128, db * 32 + 8 * g + 4 * h);
                 bf16x4 v = {(bf16)f[0], (bf16)f[1], (bf16)f[2], (bf16)f[3]};
-                *(bf16x4*)(row + db * 32 + 8 * g + 4 * h) = v;
+                attn_store4(row + db * 32 + 8 * g + 4 * h, v);
             }
     }
 }
@@ -1133,8 +1146,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
                 if (p.rope) rope_adjoint4(f, p.rope + (size_t)ki * 128, db * 32 + 8 * g + 4 * h);
                 bf16x4 a = {(bf16)f[0], (bf16)f[1], (bf16)f[2], (bf16)f[3]};
                 bf16x4 v = {(bf16)dvt[db][4 * g], (bf16)dvt[db][4 * g + 1], (bf16)dvt[db][4 * g + 2], (bf16)dvt[db][4 * g + 3]};
-                *(bf16x4*)(krow + db * 32 + 8 * g + 4 * h) = a;
-                *(bf16x4*)(vrow + db * 32 + 8 * g + 4 * h) = v;
+                attn_store4(krow + db * 32 + 8 * g + 4 * h, a);
+                attn_store4(vrow + db * 32 + 8 * g + 4 * h, v);
             }
     }
 }

@@ -41,6 +41,7 @@ struct IgemmArgs {
     // the pixel-shuffle / polyphase / parity layers spent up to 45 % of their time there (profiles/r03_kernel_experiments.txt item 19)
     unsigned dv_hw_m, dv_w_m, dv_cq_m;
     int dv_hw_s, dv_w_s, dv_cq_s;
+    int store_nt;         // register epilogues: non-temporal stores (outputs beyond the Infinity Cache; tv_set_igemm_nt_threshold)
     unsigned out_bytes;   // extent of out (and of pre / res / aux: same shape) when below 2 GiB, else 0: the register epilogues
                           // address them through buffer descriptors with 32-bit offsets
     unsigned x_bytes, w_bytes;  // MODE 2: extents of the two buffers (< 2 GiB)
@@ -336,13 +337,20 @@ __device__ __forceinline__ bf16x8 epi_math(float (&v)[8], const bf16x8& ld, cons
 #ifndef TV_EPI_BUF
 #define TV_EPI_BUF 1
 #endif
+// Cache policy of the epilogue's stores (gfx950 aux bits: 1 sc0, 2 nt, 16 sc1).  Non-temporal: the output stream of a tile is written
+// once and not read by this launch -- kept out of the way of the operands the launch re-reads through L2 / the Infinity Cache:
+// linear layers -4...-7 % in isolation, bench +0.5-0.6 % (item 23; sc1: no change).  Chosen per launch (IgemmArgs.store_nt): an
+// output small enough to stay in the 256 MiB Infinity Cache for its consumer keeps the default policy.
+#ifndef TV_EPI_LOAD_AUX
+#define TV_EPI_LOAD_AUX 0    // ... of the epilogue's residual / saved-derivative loads (read once)
+#endif
 typedef unsigned int epi_u32x4 __attribute__((__vector_size__(16)));
 #ifdef TV_EXP_GN_EPI
 __device__ float* g_gn_epi_buf = nullptr;   // timing experiment: per-wave GroupNorm partials [block][wave][256] (tv_set_gn_epi_probe)
 #endif
 __device__ __forceinline__ bf16x8 epi_bload(const void* base, unsigned bytes, int off) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const epi_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000), off, 0, 0);
+    const epi_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000), off, 0, TV_EPI_LOAD_AUX);
     return __builtin_bit_cast(bf16x8, v);
 #else
     return bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -351,6 +359,11 @@ __device__ __forceinline__ bf16x8 epi_bload(const void* base, unsigned bytes, in
 __device__ __forceinline__ void epi_bstore(void* base, unsigned bytes, int off, const bf16x8& z) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(epi_u32x4, z), __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000), off, 0, 0);
+#endif
+}
+__device__ __forceinline__ void epi_bstore_nt(void* base, unsigned bytes, int off, const bf16x8& z) {   // non-temporal (aux bit 1)
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(epi_u32x4, z), __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000), off, 0, 2);
 #endif
 }
 
@@ -406,7 +419,8 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
     };
     auto st = [&](bf16* base, int off, const bf16x8& z) {
 #if TV_EPI_BUF
-        epi_bstore(base, p.out_bytes, off, z);
+        if (p.store_nt) epi_bstore_nt(base, p.out_bytes, off, z);   // (wave-uniform)
+        else epi_bstore(base, p.out_bytes, off, z);
 #else
         if (off != OOB_OFFSET) *(bf16x8*)((char*)base + (unsigned)off) = z;
 #endif

@@ -903,6 +903,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
 }
 
 bool g_use_dma = true;
+int g_nt_threshold_mb = 64;  // epilogue stores are non-temporal for outputs of at least this many MiB (-1: never; tv_set_igemm_nt_threshold): bench 148.7 (never) / 149.4 (always) / 149.6 (64) / 149.2 (192) / 149.0 (512) images/s on one box
 int g_loop8 = 1;       // eight-phase ping-pong loop for single-tap layers on the 256 x 256 tile (tv_set_igemm_persist(-1 / -2): off / on)
 int g_persist = 0;     // persistent tile walk: 0 off (default: measured -0.3 % over the linear layers, profiles/r03_kernel_experiments.txt item 12), 1 heuristic walk length, n > 1 forced walk of n tiles
 int g_cfg_stages = 0;  // 0 = heuristic, else 2 / 3 / 4
@@ -1090,6 +1091,11 @@ extern "C" int tv_set_igemm_halo(int on) {   // 0: 3x3 stride-1 convolutions thr
     return 0;
 }
 
+extern "C" int tv_set_igemm_nt_threshold(int mib) {   // tuning hook (A/B): see g_nt_threshold_mb
+    g_nt_threshold_mb = mib;
+    return 0;
+}
+
 extern "C" int tv_set_igemm_persist(int on) {   // tuning hook (A/B timing, tests): see g_persist; -1 / -2: eight-phase loop off / on
     if (on == -1) g_loop8 = 0;
     else if (on == -2) g_loop8 = 1;
@@ -1221,6 +1227,7 @@ static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, co
     {   // extent of the output tensor (shuffled stores: 4 M pixels of N / 4 channels; the polyphase grid is smaller still)
         const long long ob = d->store_shuffle ? ((4ll * M - 1) * d->ldo + (a.N >> 2)) * 2 : ((M - 1) * (long long)d->ldo + a.N) * 2;
         a.out_bytes = ob < (1ll << 31) ? (unsigned)ob : 0u;
+        a.store_nt = (g_nt_threshold_mb >= 0 && ob >= ((long long)g_nt_threshold_mb << 20)) ? 1 : 0;
         if (a.out_bytes == 0) a.form = EF_GENERIC;   // (the register forms carry 32-bit offsets; epilogue_mode() checks the same)
     }
     hipStream_t s = (hipStream_t)stream;

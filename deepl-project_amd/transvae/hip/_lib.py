@@ -142,6 +142,10 @@ def load():
         lib.tv_set_igemm_halo.argtypes = [_I]
         lib.tv_set_igemm_epilogue.restype = _I
         lib.tv_set_igemm_epilogue.argtypes = [_I]
+        lib.tv_set_igemm_nt_threshold.restype = _I
+        lib.tv_set_igemm_nt_threshold.argtypes = [_I]
+        if os.environ.get("TV_IGEMM_NT_MB") is not None:    # A/B hook: epilogue stores non-temporal from this output size on (-1: never)
+            lib.tv_set_igemm_nt_threshold(int(os.environ["TV_IGEMM_NT_MB"]))
         lib.tv_set_igemm_persist.restype = _I
         lib.tv_set_igemm_persist.argtypes = [_I]
         lib.tv_set_attn_bwd_mask.restype = _I
