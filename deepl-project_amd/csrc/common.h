@@ -163,6 +163,13 @@ __device__ __forceinline__ void buffer_load_lds16(const void* base, unsigned byt
                                              TV_LDS(lds), 16, voff, soff, 0, 0);
 #endif
 }
+// the same with the non-temporal cache policy (aux bit 1): operand bytes a launch reads once
+__device__ __forceinline__ void buffer_load_lds16_nt(const void* base, unsigned bytes, char* lds, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000),
+                                             TV_LDS(lds), 16, voff, soff, 0, 2);
+#endif
+}
 
 // ---------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)

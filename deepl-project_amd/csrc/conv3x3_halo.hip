@@ -109,7 +109,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv3x3_halo_kernel(const Igemm
         return;
 #endif
         const int j = it * NWL + wave;
+#if TV_HALO_A_NT
+        if (j < A_PIECES) buffer_load_lds16_nt(p.x, p.x_bytes, dst + j * 1024, VOFF_REGS ? a_voff_r[VOFF_REGS ? it : 0] : a_voff_of(j), ch * (BK * 2));
+#else
         if (j < A_PIECES) buffer_load_lds16(p.x, p.x_bytes, dst + j * 1024, VOFF_REGS ? a_voff_r[VOFF_REGS ? it : 0] : a_voff_of(j), ch * (BK * 2));
+#endif
     };
     auto issue_b_piece = [&](char* dst, int it, int koff) {
 #ifdef TV_ABL_NO_DMA

@@ -95,6 +95,9 @@ using namespace tvi;
 #ifndef TV_P8_B0PF
 #define TV_P8_B0PF 1       // eight-phase GEMM loop: B0 fragments resident for both of their quadrants, the next K-step's read in phase 4
 #endif
+#ifndef TV_HALO_A_NT
+#define TV_HALO_A_NT 0     // halo pieces (activations, read ~1.1 times per launch) with the non-temporal policy: A/B in item 24
+#endif
 #ifndef TV_HALO_P8
 #define TV_HALO_P8 0       // halo ping-pong loop in four phases of 12 MFMAs per tap step (one DMA piece per load section) instead of two: measured 8-11 % SLOWER (profiles/r03_kernel_experiments.txt item 15), kept for A/B
 #endif
