@@ -95,7 +95,7 @@ def time_dominant_kernel(mb: int, res: int, dev):
             j = json.load(f)["conv3x3_halo"]
         traffic = round(j["hbm_bytes_per_launch"] * mb / j["images"])
         traffic_src = "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --kernel-only`, gfx950 corrections applied; not measured inside this run)"
-    return {"bound": "mfma", "kernel": "conv3x3_halo_kernel<256,192,4,2,3,0> via tv_igemm_nt (conv3x3 192->192 @%dx%d, %d images; ping-pong main loop)" % (res, res, mb),
+    return {"bound": "mfma", "kernel": "conv3x3_halo_kernel (the instantiation tv_igemm_nt selects) via tv_igemm_nt (conv3x3 192->192 @%dx%d, %d images)" % (res, res, mb),
             "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
             "traffic": traffic, "traffic_source": traffic_src,
@@ -124,7 +124,7 @@ def time_linear_kernel(mb: int, dev):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     flop = 2.0 * M * K * N
-    return {"bound": "mfma", "kernel": "igemm_nt_kernel<256,256,2,4,64,2,2,0; eight-phase loop> via tv_igemm_nt (linear 1536->6144, %d rows = %d images x 256 tokens)" % (M, mb),
+    return {"bound": "mfma", "kernel": "igemm_nt_kernel (the instantiation tv_igemm_nt selects) via tv_igemm_nt (linear 1536->6144, %d rows = %d images x 256 tokens)" % (M, mb),
             "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
             "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": (M * K + M * N + N * K) * 2}
@@ -140,6 +140,8 @@ def time_wgrad_kernel(mb: int, res: int, dev):
     w = torch.zeros(C, 3, 3, C, device=dev)
     geo = ops._Geo("c3s1", x, w)
     dw, db = ops.conv_wgrad_alloc(geo, w, True, x, gy)
+    dw.zero_()          # wgrad_acc ADDS: never accumulate into uninitialised memory (NaN / Inf operands would perturb the timing)
+    db.zero_()
     d = geo.fwd_desc(0)
     for _ in range(10):
         ops.wgrad_acc(d, x, gy, dw, db)
@@ -160,16 +162,18 @@ def time_wgrad_kernel(mb: int, res: int, dev):
         if j:
             traffic = round(j["hbm_bytes_per_launch"] * mb / j["images"])
             traffic_src = "profiles/r03_dominant_kernel_pmc_all.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --kernel-only`, gfx950 corrections applied; not measured inside this run)"
-    return {"bound": "mfma", "kernel": "wgrad_kx3_kernel<192,96,4,2,4,4,64> via tv_wgrad_tn_acc (weight + bias gradient of conv3x3 192->192 @%dx%d, %d images)" % (res, res, mb),
+    return {"bound": "mfma", "kernel": "wgrad_kx3_kernel (the instantiation tv_wgrad_tn_acc selects) via tv_wgrad_tn_acc (weight + bias gradient of conv3x3 192->192 @%dx%d, %d images)" % (res, res, mb),
             "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": 2 * mb * res * res * C * 2 + 9 * C * C * 4}
 
 
-def cpu_baseline(variant: str, res: int, threads: int, lr: float):
-    """The oracle (CPU restatement of the reference path) on ONE image: the SAME step as the GPU leg -- forward with the
-    P/ clamps, L1 + 1e-8 KL with the logvar clamp, backward, clip-norm 1.0, AdamW at the warm-up learning rate."""
+def cpu_baseline(variant: str, res: int, threads: int, lr: float, batch: int = 2, timed_steps: int = 2):
+    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload, SURVEY 8d: a micro-batch
+    of `batch` images through the SAME step as the GPU leg -- forward with the P/ clamps, L1 + 1e-8 KL with the logvar
+    clamp, backward, clip-norm 1.0, AdamW at the warm-up learning rate -- ONE untimed warm-up step (first-touch allocation,
+    thread-pool start) and then `timed_steps` timed steps; images/s = batch * timed_steps / time."""
     from oracle import transvae_oracle as O
     torch.set_num_threads(threads)
     cfg = O.variant_config(variant, 16, 32)
@@ -191,18 +195,31 @@ def cpu_baseline(variant: str, res: int, threads: int, lr: float):
         sd[k] = t.requires_grad_(True)
     params = [v for v in sd.values() if v.requires_grad]
     opt = torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.95), weight_decay=0.0)
-    x = torch.rand(1, 3, res, res, generator=g)
-    eps = torch.randn(1, 32, res // 16, res // 16, generator=g)
+    x = torch.rand(batch, 3, res, res, generator=g)
+    eps = torch.randn(batch, 32, res // 16, res // 16, generator=g)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        recon, mu, logvar = O.forward(x, sd, cfg, eps, clamp=True)
+        loss = O.bench_loss(recon, x, mu, logvar, clamp_logvar=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        return float(loss)
     t0 = time.time()
-    recon, mu, logvar = O.forward(x, sd, cfg, eps, clamp=True)
-    loss = O.bench_loss(recon, x, mu, logvar, clamp_logvar=True)
-    loss.backward()
-    torch.nn.utils.clip_grad_norm_(params, 1.0)
-    opt.step()
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"1 image, TransVAE-{variant} f16d32 {res}x{res}, fp32 oracle fwd+bwd+clip+AdamW "
-                      f"(same clamps / loss / optimizer as the GPU leg), {dt:.1f} s",
+    step()
+    warm = time.time() - t0
+    times = []
+    for _ in range(timed_steps):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    dt = sum(times)
+    return {"value": round(batch * timed_steps / dt, 5), "unit": "images/sec", "cores": threads, "host_cores": os.cpu_count(),
+            "kind": "port",
+            "sample": f"micro-batch of {batch} images, TransVAE-{variant} f16d32 {res}x{res}, fp32 oracle fwd+bwd+clip+AdamW "
+                      f"(same clamps / loss / optimizer as the GPU leg): 1 warm-up step ({warm:.1f} s) + {timed_steps} timed steps "
+                      f"({', '.join('%.1f' % t for t in times)} s), {threads} torch threads on a host of {os.cpu_count()} logical cores",
             # the reference's OWN fp32 CPU path cannot travel to the GPU box; timed in the build container
             "reference_cpu_path": {"value": 0.019, "unit": "images/sec", "cores": 8, "where": "build container (8 cores)",
                                    "sample": "TransVAE-large f16d32 256x256, batch 2, fwd+bwd+clip+AdamW, 104.7 s/step"}}
@@ -232,8 +249,23 @@ def main():
                     help="N > 1: gradient all-reduce in fp32 (4.2 GB per step, the reference's DDP) or with bf16 buckets (2.1 GB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-batch", type=int, default=2, help="images per step of the CPU baseline (SURVEY 8d: 2-4)")
+    ap.add_argument("--dist-backend", choices=["auto", "nccl", "gloo", "none"], default="auto",
+                    help="auto: nccl (= RCCL) whenever the process was started by torch.distributed.run (RANK / WORLD_SIZE in the "
+                         "environment), also with ONE rank -- DDP, its bucket views and the all-reduce then run exactly as at N > 1; "
+                         "none with a plain `python bench.py`")
+    ap.add_argument("--allow-tuning-env", action="store_true",
+                    help="run although TV_* tuning variables are set (they are printed into config.tuning_env either way)")
     ap.add_argument("--kernel-only", action="store_true", help="only time the dominant kernel (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
+    # read at HSA initialisation: must be in the environment BEFORE the first torch.cuda call of this process (the image exports
+    # it already; this is the default for a bare shell).  dmabuf IPC is the only mode the host driver supports.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # process-global tuning hooks of the library (transvae/hip/_lib.py) change the timed path: refuse them unless asked for
+    tuning_env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("TV_") and k not in ("TV_BENCH_REHEARSE",)}
+    if tuning_env and not args.allow_tuning_env:
+        raise SystemExit(f"bench.py: tuning variables are set ({tuning_env}); unset them or pass --allow-tuning-env "
+                         "(they are then reported in config.tuning_env)")
     if args.kernel_only:
         torch.cuda.set_device(0)
         r = time_dominant_kernel(args.micro_batch, args.res, torch.device("cuda", 0))
@@ -255,12 +287,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    backend = args.dist_backend
+    if backend == "auto":
+        backend = "gloo" if rehearse else ("nccl" if (world > 1 or launched) else "none")
+    if world > 1 and backend == "none":
+        raise SystemExit("--dist-backend none with more than one rank")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)      # RCCL on ROCm
+    elif backend == "gloo":
+        dist.init_process_group("gloo")
 
     from transvae import TransVAE
     from transvae.hip import _lib
@@ -274,7 +310,7 @@ def main():
     if args.checkpointing != "off":
         model.enable_gradient_checkpointing(args.checkpointing)
     model.train()
-    ddp = wrap_ddp(model, dev, grad_exchange=args.grad_exchange)
+    ddp = wrap_ddp(model, dev, grad_exchange=args.grad_exchange, force=backend != "none")
     if args.optimizer == "hip":
         from transvae.optim import FusedAdamW
         opt = FusedAdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.95), weight_decay=0.0)
@@ -296,7 +332,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if backend != "none":
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -330,12 +366,13 @@ def main():
             log(f"step {i} queued")
     sync()
     dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    if world > 1:
+    if backend != "none":
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt)
     # every step's loss (all ranks' shares summed) and the number of skipped steps
     lt = torch.stack([l.float() for l in losses])
-    if world > 1:      # train_step weights a rank's loss by world_size (DDP averages gradients): the mean over ranks is the loss
+    if backend != "none":      # train_step weights a rank's loss by world_size (DDP averages gradients): the mean over ranks is the loss
+        lt = lt.to(dev)
         dist.all_reduce(lt)
         lt /= world
     lt = lt.cpu()
@@ -346,7 +383,7 @@ def main():
         if rank == 0:
             log(f"FAILED: non-finite loss or skipped steps (skipped {skipped:.0f}); per-step losses: "
                 + " ".join(f"{float(v):.4g}" for v in lt))
-        if world > 1:
+        if backend != "none":
             dist.barrier()
             dist.destroy_process_group()
         sys.exit(3)
@@ -367,7 +404,10 @@ def main():
             "config": {"workload": f"TransVAE-{args.variant} f16d32 {res_name} train step "
                                    f"(fwd+bwd+grad all-reduce+clip+AdamW), global batch {args.global_batch}",
                        "global_batch": args.global_batch, "micro_batch": [micro[r] for r in resolutions] if len(resolutions) > 1 else args.micro_batch,
-                       "parallelism": f"dp{world}", "gradient_exchange": args.grad_exchange if world > 1 else None,
+                       "parallelism": f"dp{world}", "gradient_exchange": args.grad_exchange if backend != "none" else None,
+                       "dist_backend": {"nccl": "nccl (RCCL), DistributedDataParallel", "gloo": "gloo (one-GPU rehearsal), DistributedDataParallel",
+                                        "none": "none (single process, no process group)"}[backend],
+                       "tuning_env": tuning_env,
                        "weights": "random fan-in scaled", "loss": "L1 + 1e-8 KL (vae_loss.py:83-84,94-96)",
                        "numerics": "P/ clamps on mu/logvar, skip-on-non-finite guard",
                        "checkpointing": args.checkpointing,
@@ -387,13 +427,13 @@ def main():
         # the largest weight-gradient kernel (9 %) is reported beside it
         out["roofline"]["also"] = [time_wgrad_kernel(min(args.micro_batch, count), 256, dev), time_linear_kernel(min(args.micro_batch, count), dev)]
         if world == 1 and not args.no_cpu_baseline:
-            log("cpu baseline (oracle, 1 image) ...")
+            log("cpu baseline (oracle: 1 warm-up + 2 timed steps) ...")
             del model, ddp, opt
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args.variant, resolutions[0], max(1, min(args.cpu_threads, os.cpu_count() or 1)),
-                                               warmup_lr(args.lr, 0, args.lr_warmup_steps))
+                                               warmup_lr(args.lr, 1, args.lr_warmup_steps), batch=args.cpu_batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if backend != "none":
         dist.barrier()
         dist.destroy_process_group()
 

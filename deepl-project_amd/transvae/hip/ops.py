@@ -609,8 +609,10 @@ def conv_dgrad(g: _Geo, w, gz, x_shape, residual=None, aux=None, aux_act: int = 
 
 
 def _wgrad_overwrites(desc: L.ConvDesc) -> bool:
-    """True when tv_wgrad_tn writes every element of dw / dbias exactly once for this geometry (no pre-zeroing needed).
-    The answer follows the kernel's split-K choice (and its tuning hooks), so the library is asked every time."""
+    """True when tv_wgrad_tn writes every element of dw exactly once for this geometry (dw needs no pre-zeroing).  dbias is
+    NOT covered by the answer: it is always ADDED to with fp32 atomics (include/transvae_hip.h) and must be passed zeroed or
+    holding a running sum.  The answer follows the kernel's split-K choice (and its tuning hooks), so the library is asked
+    every time."""
     r = L.load().tv_wgrad_tn_overwrites(C.byref(desc))
     if r < 0:
         raise RuntimeError("tv_wgrad_tn_overwrites: bad descriptor")

@@ -245,8 +245,8 @@ def train_step(ddp_model: nn.Module, optimizer: torch.optim.Optimizer, x_local: 
             last = i == len(chunks) - 1
             sync_ctx = contextlib.nullcontext() if (last or not hasattr(ddp_model, "no_sync")) else ddp_model.no_sync()
             # in-place accumulation hands autograd no gradient for those parameters, so DDP's hooks would not fire: never on
-            # the micro-batch that synchronises
-            with sync_ctx, _accumulate_in_place(x_local, i > 0 and (world == 1 or not last)):
+            # the micro-batch that synchronises (also with ONE rank when the model is DDP-wrapped: wrap_ddp(force=True))
+            with sync_ctx, _accumulate_in_place(x_local, i > 0 and (not hasattr(ddp_model, "no_sync") or not last)):
                 loss = forward_loss(ddp_model, x_local[s:s + c]) * (c * world / global_batch)
                 loss.backward()
             total += loss.detach()

@@ -622,6 +622,153 @@ def schemas_more():
     print("param counts", counts)
 
 
+LARGE_STEP_KEYS = [
+    "encoder.conv_in.weight", "encoder.stages.0.0.conv1.weight", "encoder.stages.1.2.norm2.weight",
+    "encoder.downsamples.0.main_path.2.weight", "encoder.stages.2.0.attn.to_q.weight", "encoder.stages.2.0.attn.norm_k.bias",
+    "encoder.stages.3.1.ffn.proj_in.weight", "encoder.stages.4.5.ffn.conv.2.weight", "conv_logvar.weight",
+    "decoder.conv_in.weight", "decoder.stages.0.3.attn.proj.weight", "decoder.upsamples.3.main_path.1.weight",
+    "decoder.stages.4.2.conv2.bias", "decoder.conv_out.weight",
+]
+
+
+def large_steps():
+    """BASELINE config 2's UNIT OF WORK pinned to the reference: TWO optimizer steps of TransVAE-Large f16d32 on ONE 256 x 256
+    image per step, through the reference's patched model (P/.../transvae.py:186-196,243-245: the clamps the bench runs
+    with) and the reference trainer's step (R/train.py:577-620,681-687: loss -> backward -> clip_grad_norm_(1.0) ->
+    torch.optim.AdamW(lr 1e-4, betas (0.9, 0.95), weight_decay 0); loss = L1 + 1e-8 KL with the logvar clamp of
+    R/train_2.py:316-318), fp32 on the CPU, filler weights + LARGE_GAINS.  Recorded per step: loss, gradient norm before the
+    clip, and for 14 named tensors 256 sampled gradient values and the parameter delta (p_after - p_before) at the same
+    indices.  Then the same two steps under torch.autocast(cpu, bf16) from the same start: the reference's OWN bf16
+    deviation of every recorded quantity (the yardstick of the bf16 tier)."""
+    import time
+    P = import_reference(patched=True)
+
+    def two_steps(autocast):
+        model = _large_model(P)
+        model.train()
+        params = dict(model.named_parameters())
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0)
+        idx = {k: torch.randperm(params[k].numel(), generator=torch.Generator().manual_seed(zlib_crc("steps:" + k)))[:256]
+               for k in LARGE_STEP_KEYS}
+        rec = {}
+        orig = torch.randn_like
+        for step in range(2):
+            x = filler.rand_input(f"largesteps.x{step}", (1, 3, 256, 256))
+            eps = filler.randn_input(f"largesteps.eps{step}", (1, 32, 16, 16))
+            before = {k: params[k].detach().flatten()[idx[k]].clone() for k in LARGE_STEP_KEYS}
+            opt.zero_grad(set_to_none=True)
+            torch.randn_like = lambda t, **kw: eps.to(t.dtype)
+            t0 = time.time()
+            try:
+                if autocast:
+                    with torch.autocast("cpu", dtype=torch.bfloat16):
+                        recon, mu, logvar = model(x)
+                else:
+                    recon, mu, logvar = model(x)
+            finally:
+                torch.randn_like = orig
+            loss = O.bench_loss(recon.float(), x, mu.float(), logvar.float(), clamp_logvar=True)
+            loss.backward()
+            norm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            grads = {k: params[k].grad.detach().flatten()[idx[k]].clone() for k in LARGE_STEP_KEYS}
+            gl2 = {k: float(params[k].grad.double().norm()) for k in LARGE_STEP_KEYS}      # (after the clip, as the optimizer sees them)
+            opt.step()
+            print("large-steps %s step %d: loss %.6f grad-norm %.4f  %.1f s" % ("bf16" if autocast else "fp32", step, float(loss),
+                                                                            float(norm), time.time() - t0), flush=True)
+            rec[f"loss{step}"] = float(loss)
+            rec[f"gnorm{step}"] = float(norm)
+            for k in LARGE_STEP_KEYS:
+                rec[f"s{step}.g:{k}"] = grads[k]
+                rec[f"s{step}.gl2:{k}"] = gl2[k]
+                rec[f"s{step}.d:{k}"] = params[k].detach().flatten()[idx[k]] - before[k]
+        return rec, idx
+    r32, idx = two_steps(False)
+    out = {}
+    for k, v in r32.items():
+        out[k] = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+    for k, i in idx.items():
+        out[f"idx:{k}"] = i.numpy()
+    np.savez_compressed(os.path.join(OUT, "large_two_steps.npz"), **out)
+    r16, _ = two_steps(True)
+    dev = {}
+    for k, v in r32.items():
+        if torch.is_tensor(v):
+            n = float(v.double().norm())
+            dev[k] = float((r16[k].double() - v.double()).norm() / n) if n > 0 else 0.0
+        else:
+            dev[k] = abs(r16[k] - v) / abs(v)
+    dev["loss_bf16"] = [r16["loss0"], r16["loss1"]]
+    dev["gnorm_bf16"] = [r16["gnorm0"], r16["gnorm1"]]
+    print("reference bf16-autocast deviation over two Large steps:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in dev.items()})
+    with open(os.path.join(OUT, "large_two_steps_ref_bf16_autocast.json"), "w") as f:
+        json.dump(dev, f, indent=0)
+
+
+TINY_GRAD_KEYS = [
+    "encoder.conv_in.weight", "encoder.conv_in.bias", "encoder.stages.0.0.norm1.weight", "encoder.stages.1.0.conv2.weight",
+    "encoder.downsamples.1.dc_conv.weight", "encoder.stages.2.0.attn.to_k.weight", "encoder.stages.3.0.ffn.conv.2.weight",
+    "encoder.stages.4.0.attn.norm_q.weight", "conv_mu.weight", "conv_logvar.bias", "decoder.conv_in.weight",
+    "decoder.stages.0.0.ffn.proj_out.weight", "decoder.stages.2.0.norm2.weight", "decoder.upsamples.1.main_path.3.weight",
+    "decoder.stages.4.0.conv1.weight", "decoder.conv_out.weight",
+]
+
+
+def tiny_bs4():
+    """BASELINE config 1 at its STATED batch with the backward: tiny f16d32 (R/configs/transvae_tiny_f16d32.yaml), 256 x 256,
+    batch 4, fp32, forward + backward of L1 + 1e-8 KL through the reference on the CPU (inputs / noise / weights = the ones of
+    tiny_forward.npz): loss, 256 samples + norm of recon / mu / logvar over the whole batch, 256 samples + norm of 16 named
+    gradients; and the reference's own bf16-autocast deviation of each."""
+    import time
+    import yaml
+    R = import_reference()
+    with open(REF + "/configs/transvae_tiny_f16d32.yaml") as f:
+        tcfg = yaml.safe_load(f)["model"]
+    tm = R["TransVAE"](config=tcfg, variant="tiny", compression_ratio=16, latent_dim=32)
+    load_filled(tm, "")
+    tm.train()
+    xt = filler.rand_input("tiny.x", (4, 3, 256, 256))
+    et = filler.randn_input("tiny.eps", (4, 32, 16, 16))
+    orig = torch.randn_like
+
+    def run(autocast):
+        tm.zero_grad()
+        torch.randn_like = lambda t, **kw: et.to(t.dtype)
+        try:
+            if autocast:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    o = tm(xt, return_dict=True)
+            else:
+                o = tm(xt, return_dict=True)
+        finally:
+            torch.randn_like = orig
+        loss = O.bench_loss(o["reconstruction"].float(), xt, o["mu"].float(), o["logvar"].float())
+        loss.backward()
+        ps = dict(tm.named_parameters())
+        return ({k: o[k].detach().float().clone() for k in ("reconstruction", "mu", "logvar")}, float(loss),
+                {k: ps[k].grad.detach().clone() for k in TINY_GRAD_KEYS})
+    t0 = time.time()
+    o32, loss32, g32 = run(False)
+    print("tiny bs4 fp32 fwd+bwd %.1f s, loss %.6f" % (time.time() - t0, loss32), flush=True)
+    out = {"loss": np.asarray(loss32)}
+    for nm, key in (("recon", "reconstruction"), ("mu", "mu"), ("logvar", "logvar")):
+        _sample(out, nm, o32[key])
+    for k, g in g32.items():
+        _sample(out, "g:" + k, g)
+    np.savez_compressed(os.path.join(OUT, "tiny_bs4_fwd_bwd.npz"), **out)
+    t0 = time.time()
+    o16, loss16, g16 = run(True)
+    print("tiny bs4 bf16-autocast fwd+bwd %.1f s" % (time.time() - t0), flush=True)
+    dev = {"loss_bf16": loss16}
+    for nm, key in (("recon", "reconstruction"), ("mu", "mu"), ("logvar", "logvar")):
+        dev[nm] = float((o16[key].double() - o32[key].double()).norm() / o32[key].double().norm())
+    for k in TINY_GRAD_KEYS:
+        n = float(g32[k].double().norm())
+        dev["g:" + k] = float((g16[k].double() - g32[k].double()).norm() / n) if n > 1e-12 else 0.0
+    print("reference bf16-autocast deviation, tiny bs4:", {k: round(v, 4) for k, v in dev.items()})
+    with open(os.path.join(OUT, "tiny_bs4_ref_bf16_autocast.json"), "w") as f:
+        json.dump(dev, f, indent=0)
+
+
 def zlib_crc(k: str) -> int:
     import zlib
     return zlib.crc32(k.encode()) & 0x7FFFFFFF
@@ -642,5 +789,9 @@ if __name__ == "__main__":
         large_unit()
     elif "--schemas-more" in sys.argv:
         schemas_more()
+    elif "--large-steps" in sys.argv:  # two reference optimizer steps of Large on one 256 x 256 image, fp32 + bf16: ~10 min, ~25 GB
+        large_steps()
+    elif "--tiny-bs4" in sys.argv:     # config 1 at batch 4, forward + backward, fp32 + bf16: ~3 min
+        tiny_bs4()
     else:
         main()

@@ -363,6 +363,50 @@ def test_tiny_config1_against_reference_golden(golden_dir):
             assert abs(flat.std(ddof=1) - float(g[f"{nm}.{b}.std"])) < 2e-2 * float(g[f"{nm}.{b}.std"])
 
 
+def test_tiny_config1_batch4_forward_backward_against_reference_golden(golden_dir):
+    """BASELINE config 1 AS STATED (R/configs/transvae_tiny_f16d32.yaml, 256 x 256, batch 4): forward AND backward of
+    L1 + 1e-8 KL over the whole batch on the GPU against values minted by the reference itself
+    (oracle/make_goldens.py --tiny-bs4 -> tiny_bs4_fwd_bwd.npz: 256 sampled elements + norms of recon / mu / logvar and of 16
+    named gradients).  Tolerance: the reference's own bf16-autocast deviation on the same tensors
+    (tiny_bs4_ref_bf16_autocast.json), outputs max(1e-2, 1.25 x), gradients max(3e-2, 1.5 x) -- 256 samples estimate a
+    full-tensor rel-L2 to about +-10 %; norms to 2 %."""
+    from transvae import TransVAE
+    g = golden(golden_dir, "tiny_bs4_fwd_bwd.npz")
+    with open(os.path.join(golden_dir, "tiny_bs4_ref_bf16_autocast.json")) as f:
+        ref16 = json.load(f)
+    m = TransVAE(variant="tiny", compression_ratio=16, latent_dim=32)
+    m.load_state_dict(filler.fill_state_dict(O.state_dict_schema(O.variant_config("tiny", 16, 32), 32)))
+    m = m.to(DEV)
+    m.train()
+    x = filler.rand_input("tiny.x", (4, 3, 256, 256)).to(DEV)
+    eps = filler.randn_input("tiny.eps", (4, 32, 16, 16)).to(DEV)
+    recon, mu, logvar = m(x, eps=eps)
+    loss = O.bench_loss(recon, x, mu, logvar)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 5e-3 * float(g["loss"]), (float(loss), float(g["loss"]))
+
+    def sampled_err(name, t):
+        flat = t.detach().flatten().double().cpu().numpy()
+        got, ref = flat[g[f"{name}.idx"]], g[f"{name}.val"].astype(np.float64)
+        return (float(np.linalg.norm(got - ref) / np.linalg.norm(ref)),
+                abs(float(np.linalg.norm(flat)) - float(g[f"{name}.l2"])) / float(g[f"{name}.l2"]))
+    report = {}
+    for nm, t in (("recon", recon), ("mu", mu), ("logvar", logvar)):
+        e, en = sampled_err(nm, t)
+        report[nm] = (round(e, 4), round(ref16[nm], 4))
+        assert e < max(1e-2, 1.25 * ref16[nm]), (nm, e, ref16[nm])
+        assert en < 2e-2, (nm, en)
+    params = dict(m.named_parameters())
+    keys = [k[2:-4] for k in g if k.startswith("g:") and k.endswith(".idx")]
+    assert len(keys) == 16
+    for k in keys:
+        e, en = sampled_err("g:" + k, params[k].grad)
+        report["g:" + k] = (round(e, 4), round(ref16["g:" + k], 4))
+        assert e < max(3e-2, 1.5 * ref16["g:" + k]), (k, e, ref16["g:" + k])
+        assert en < max(3e-2, 1.5 * ref16["g:" + k]), (k, en)
+    print("tiny f16d32 batch 4, sampled rel-L2 (ours, reference's own bf16-autocast deviation):", report)
+
+
 def test_large_f16d32_256_full_size_properties_and_oracle():
     """BASELINE config 1 at its full size (TransVAE-Large f16d32, 256 x 256; the bench's weight rule): the oracle on one
     image, plus the size-independent properties of the path -- images do not see each other (a batch equals its images

@@ -204,6 +204,32 @@ def test_tiny_config1_forward(golden_dir):
         assert abs(flat.std(ddof=1) - float(g[f"{nm}.0.std"])) < 1e-4 * float(g[f"{nm}.0.std"]), nm
 
 
+def test_tiny_config1_batch4_forward_backward(golden_dir):
+    """BASELINE config 1 at its stated batch (tiny f16d32, 256 x 256, batch 4, fp32) WITH the backward: the oracle against
+    the reference's sampled outputs and gradients (tiny_bs4_fwd_bwd.npz from `oracle/make_goldens.py --tiny-bs4`)."""
+    g = load(golden_dir, "tiny_bs4_fwd_bwd.npz")
+    cfg = O.variant_config("tiny", 16, 32)
+    keys = [k[2:-4] for k in g if k.startswith("g:") and k.endswith(".idx")]
+    sd = {k: v.requires_grad_(k in keys) for k, v in filler.fill_state_dict(O.state_dict_schema(cfg, 32)).items()}
+    x = filler.rand_input("tiny.x", (4, 3, 256, 256))
+    eps = filler.randn_input("tiny.eps", (4, 32, 16, 16))
+    torch.set_num_threads(8)
+    recon, mu, logvar = O.forward(x, sd, cfg, eps)
+    loss = O.bench_loss(recon, x, mu, logvar)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    for nm, t in (("recon", recon), ("mu", mu), ("logvar", logvar)):
+        flat = t.detach().flatten().double().numpy()
+        ref = g[f"{nm}.val"].astype(np.float64)
+        assert np.linalg.norm(flat[g[f"{nm}.idx"]] - ref) < 1e-4 * np.linalg.norm(ref), nm
+        assert abs(np.linalg.norm(flat) - float(g[f"{nm}.l2"])) < 1e-5 * float(g[f"{nm}.l2"]), nm
+    for k in keys:
+        flat = sd[k].grad.flatten().double().numpy()
+        ref = g[f"g:{k}.val"].astype(np.float64)
+        assert np.linalg.norm(flat[g[f"g:{k}.idx"]] - ref) < 2e-3 * np.linalg.norm(ref) + 1e-12, k
+        assert abs(np.linalg.norm(flat) - float(g[f"g:{k}.l2"])) < 1e-3 * float(g[f"g:{k}.l2"]) + 1e-12, k
+
+
 def test_oracle_large_forward_matches_reference_golden(golden_dir):
     """TransVAE-Large f16d32 at 256 x 256 (BASELINE config 2's model at full size), one image, forward: the oracle against
     the reference's sampled outputs (tests/golden/large_one_image.npz from `oracle/make_goldens.py --large`).  The backward
