@@ -27,6 +27,7 @@ struct IgemmArgs {
     int h_out, w_out, ldo;
     int kh, kw, stride, pad, up_shift, dil_mask;
     int tiles_n, tiles_m, xcd_order;
+    int sup_r, sup_c;  // xcd_order 2: the blocks an XCD runs side by side form sup_r x sup_c super-tiles (row tiles x column tiles)
     int tpb, nchunks;  // persistent column loop: a block walks `tpb` consecutive column tiles of its row tile (nchunks = tiles_n / tpb)
     int shuffle;
     int act;

@@ -29,6 +29,7 @@ int g_cfg_bn = 0;      // 0 = heuristic, 256 = 256-wide N tiles whenever c_out %
 int g_halo_ring = 3;    // weight ring depth of the halo kernel (2 / 3; 3 falls back to 2 where the LDS is too small)
 bool g_halo_w4 = false;   // experiment: 256x192 halo tile with 4 waves (one per SIMD, 128x96 wave tiles)
 bool g_xcd_order = true;  // column tiles of a row tile on one XCD (block order in the kernels)
+int g_supertile = 0;      // 8-wave GEMM tiles: 0 = super-tile block order chosen per shape, 1 = row-tile-major (round 3), r * 100 + c = forced
 bool g_epi_modes = true;   // compile-time epilogue forms (tv_set_igemm_epilogue(0): the generic one everywhere, for A/B timing)
 
 // which epilogue form a call takes (see epilogue<>): 1 = residual add only, 2 = saved-derivative multiply, 0 = the rest
@@ -156,6 +157,21 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
         const int r = walk_i / p.tiles_n;
         tile_n = walk_i - r * p.tiles_n;
         tile_m = r * 8 + walk_x;
+    } else if (p.xcd_order == 2) {
+        // Super-tile order (round 4).  An XCD runs ~32 blocks side by side; in the row-tile-major order above those are the
+        // tiles_n column tiles of ONE row tile, which share the row panel through the XCD's L2 and NOTHING of the weights:
+        // every row tile re-streams the whole weight matrix from beyond L2 (1536 -> 6144, 64 images: 64 x 18.9 MB = 1.2 GB
+        // per launch for 69 MB of operands, profiles/r03_p8_gemm_pmc.json).  Here consecutive ids of an XCD form sup_r x sup_c
+        // super-tiles: a row panel is shared by sup_c blocks and a weight panel by sup_r, and since the blocks of a super-tile
+        // start together and advance along K in step, the XCD's L2 only has to hold the K-window they are in.
+        const int lin = blockIdx.x, j = lin >> 3, per = p.sup_r * p.sup_c;
+        const int sidx = (j / per) * 8 + (lin & 7), w = j % per;
+        const int nsn = (p.tiles_n + p.sup_c - 1) / p.sup_c;
+        const int sm = sidx / nsn, sn = sidx - sm * nsn;
+        const int dr = w / p.sup_c;
+        tile_m = sm * p.sup_r + dr;
+        tile_n = sn * p.sup_c + (w - dr * p.sup_c);
+        if (tile_m >= p.tiles_m || tile_n >= p.tiles_n) return;
     } else if (p.xcd_order) {
         const int lin = blockIdx.x, j = lin >> 3;
         tile_n = j % p.tiles_n;
@@ -953,8 +969,35 @@ int launch_one(const IgemmArgs& a_in, hipStream_t s) {
         a.xcd_order = (g_xcd_order && a.tiles_n > 1) ? 1 : 0;
         a.tpb = 1;
         a.nchunks = a.tiles_n;
+        a.sup_r = 1;
+        a.sup_c = a.tiles_n;
         constexpr bool POK = igemm_persist_ok<BM, BN, WGM, WGN, BK, STAGES, MODE>() && BM == 256 && BN == 256 && BK == 64;
         dim3 grid((unsigned)(a.xcd_order ? 8 * a.tiles_n * ((tiles_m + 7) / 8) : tiles_m * a.tiles_n)), block(WGM * WGN * 64);
+        if (a.xcd_order && g_supertile != 1 && (WGM * WGN == 8)) {
+            // one block per CU (8-wave tiles): 32 block slots per XCD.  Measured (tools/probes/ab_supertile.py, same process,
+            // interleaved; profiles/r04_kernel_experiments.txt): with 16 or more column tiles (N >= 4096: the 1536 -> 6144 and
+            // 1536 -> 4608 layers and the data gradients of their transposes) the 4 x 8 super-tile is 3-5 % faster than the
+            // row-tile-major order; with 12 or fewer column tiles the row-tile-major order already puts 3-5 row tiles of an XCD
+            // side by side and is as fast or faster (ragged super-tiles cost up to 20 %), so it stays
+            int br = 1, bc = a.tiles_n;
+            if (g_supertile > 1) {          // (tuning hook: forced shape r * 100 + c)
+                br = g_supertile / 100;
+                bc = g_supertile % 100;
+            } else if (a.tiles_n >= 16 && tiles_m >= 4) {
+                br = 4;
+                bc = 8;
+            }
+            if (br < 1) br = 1;
+            if (bc < 1) bc = 1;
+            if (bc > a.tiles_n) bc = a.tiles_n;
+            if (!(br == 1 && bc == a.tiles_n)) {
+                a.xcd_order = 2;
+                a.sup_r = br;
+                a.sup_c = bc;
+                const int nsup = ((tiles_m + br - 1) / br) * ((a.tiles_n + bc - 1) / bc);
+                grid = dim3((unsigned)(8 * br * bc * ((nsup + 7) / 8)));
+            }
+        }
         if constexpr (POK) {
             // tile walk: W tiles per block, P blocks per XCD label (tpb = W, nchunks = P).  The LDS epilogue parks the tile in the
             // stage buffers a prefetch would be landing in, ragged row tiles would stage rows past the tensor: one tile per block
@@ -1100,6 +1143,11 @@ extern "C" int tv_set_igemm_persist(int on) {   // tuning hook (A/B timing, test
     if (on == -1) g_loop8 = 0;
     else if (on == -2) g_loop8 = 1;
     else g_persist = on;
+    return 0;
+}
+
+extern "C" int tv_set_igemm_supertile(int v) {   // tuning hook (A/B timing, tests): see g_supertile
+    g_supertile = v;
     return 0;
 }
 
