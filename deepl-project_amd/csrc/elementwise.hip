@@ -176,6 +176,57 @@ inline int ew_grid(long long n) {
     return (int)g;
 }
 
+
+// ---- operands derived from a 3x3 weight by sums of taps (polyphase up-conv, its adjoint, the parity form of the stride-2 data
+// gradient) and the fold of the 4x4 adjoint's weight gradient back onto the 3x3 taps: out[tap_o] = sum_j in[tap_j], optionally
+// transposed ([A][Tin][B] -> [B][..][A]).  One launch instead of 20-60 slice adds / copies of torch (transvae/hip/ops.py: the
+// polyphase algebra ran ~600 small kernels per optimizer step).  Sums run in the order of the table = the order of the torch
+// expression they replace (ky outer, kx inner): bit-identical.
+struct TapSumTable {
+    int n[16];
+    int taps[16][4];
+    long long base[16];   // element offset of output tap t
+};
+
+template <typename OutT, bool TRANSPOSE, bool ACC>
+__global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ src, OutT* __restrict__ dst, const TapSumTable tab, int A, int Tin,
+                                                     int Bd, long long stride_out) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int n = tab.n[t];
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int a = a0 + r, b = b0 + tx;
+        float v = 0.f;
+        if (a < A && b < Bd) {
+            for (int j = 0; j < n; ++j) {
+                const float u = src[((size_t)a * Tin + tab.taps[t][j]) * Bd + b];
+                v = j == 0 ? u : v + u;
+            }
+            if constexpr (!TRANSPOSE) {
+                OutT* q = dst + tab.base[t] + (long long)a * stride_out + b;
+                if constexpr (ACC) *q = (OutT)((float)*q + v);
+                else *q = (OutT)v;
+            }
+        }
+        if constexpr (TRANSPOSE) tile[r][tx] = v;
+    }
+    if constexpr (TRANSPOSE) {
+        __syncthreads();
+#pragma unroll
+        for (int r = ty; r < 32; r += 8) {
+            const int b = b0 + r, a = a0 + tx;
+            if (a < A && b < Bd) {
+                OutT* q = dst + tab.base[t] + (long long)b * stride_out + a;
+                if constexpr (ACC) *q = (OutT)((float)*q + tile[tx][r]);
+                else *q = (OutT)tile[tx][r];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int tv_pack_weight(const float* src, void* dst, void* dst_t, int O, int T, int I, int flip_taps, void* stream) {
@@ -184,6 +235,80 @@ extern "C" int tv_pack_weight(const float* src, void* dst, void* dst_t, int O, i
     TV_CHECK_ARG(grid.y <= 65535, "tv_pack_weight: O too large");
     hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (bf16*)dst_t, O, T, I, flip_taps);
     TV_CHECK_LAUNCH("tv_pack_weight");
+    return TV_OK;
+}
+
+extern "C" int tv_conv3x3_derived(const float* src, void* dst, int form, int c_out, int c_in, int accumulate, void* stream) {
+    TV_CHECK_ARG(src && dst && c_out > 0 && c_in > 0 && form >= TV_DERIVE_UP_FWD && form <= TV_DERIVE_S2_PARITY,
+                 "tv_conv3x3_derived: bad arguments form=%d c_out=%d c_in=%d", form, c_out, c_in);
+    TV_CHECK_ARG(!accumulate || form == TV_DERIVE_UP_WGRAD_FOLD, "tv_conv3x3_derived: only the weight-gradient fold accumulates");
+    static const int up_sets[2][2][2] = {{{0, -1}, {1, 2}}, {{0, 1}, {2, -1}}};   // [phase][tap] -> ky (or kx) folded in (ops.py _UP_SETS)
+    static const int up_adj[4][2] = {{2, -1}, {1, 2}, {0, 1}, {0, -1}};            // adjoint tap t -> ky (ops.py _UP_ADJ)
+    static const int fold_taps[3][2] = {{2, 3}, {1, 2}, {0, 1}};                   // 3x3 tap k <- adjoint taps containing it
+    TapSumTable tab = {};
+    int nt = 0, A = c_out, Tin = 9, Bd = c_in;
+    long long stride = 0;
+    auto add = [&](int t, const int* ys, const int* xs, int tin_w) {
+        int n = 0;
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                if (ys[i] >= 0 && xs[j] >= 0) tab.taps[t][n++] = ys[i] * tin_w + xs[j];
+        tab.n[t] = n;
+    };
+    if (form == TV_DERIVE_UP_FWD) {              // [Cout,3,3,Cin] -> bf16 [4*Cout,2,2,Cin]
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px)
+                for (int ty = 0; ty < 2; ++ty)
+                    for (int tx = 0; tx < 2; ++tx) {
+                        add(nt, up_sets[py][ty], up_sets[px][tx], 3);
+                        tab.base[nt++] = ((long long)(2 * py + px) * c_out * 4 + (ty * 2 + tx)) * c_in;
+                    }
+        stride = 4LL * c_in;
+    } else if (form == TV_DERIVE_UP_DGRAD) {     // [Cout,3,3,Cin] -> bf16 [Cin,4,4,Cout]
+        for (int ty = 0; ty < 4; ++ty)
+            for (int tx = 0; tx < 4; ++tx) {
+                add(nt, up_adj[ty], up_adj[tx], 3);
+                tab.base[nt++] = (long long)(ty * 4 + tx) * c_out;
+            }
+        stride = 16LL * c_out;
+    } else if (form == TV_DERIVE_UP_WGRAD_FOLD) {   // fp32 [Cin,4,4,Cout] -> fp32 [Cout,3,3,Cin]
+        A = c_in;
+        Tin = 16;
+        Bd = c_out;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                add(nt, fold_taps[ky], fold_taps[kx], 4);
+                tab.base[nt++] = (long long)(ky * 3 + kx) * c_in;
+            }
+        stride = 9LL * c_in;
+    } else {                                     // TV_DERIVE_S2_PARITY: [Cout,3,3,Cin] -> bf16 [4*Cin,2,2,Cout]
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px)
+                for (int ty = 0; ty < 2; ++ty)
+                    for (int tx = 0; tx < 2; ++tx) {
+                        if (ty <= py && tx <= px) {
+                            const int ky = py == 0 ? 1 : (ty == 0 ? 2 : 0), kx = px == 0 ? 1 : (tx == 0 ? 2 : 0);
+                            tab.taps[nt][0] = ky * 3 + kx;
+                            tab.n[nt] = 1;
+                        } else {
+                            tab.n[nt] = 0;       // outside the class's footprint: zeros
+                        }
+                        tab.base[nt++] = ((long long)(2 * py + px) * c_in * 4 + (ty * 2 + tx)) * c_out;
+                    }
+        stride = 4LL * c_out;
+    }
+    dim3 grid(tv_cdiv(Bd, 32), tv_cdiv(A, 32), nt);
+    TV_CHECK_ARG(grid.y <= 65535, "tv_conv3x3_derived: channel count too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (form == TV_DERIVE_UP_FWD)
+        hipLaunchKernelGGL((tapsum_kernel<bf16, false, false>), grid, dim3(256), 0, s, src, (bf16*)dst, tab, A, Tin, Bd, stride);
+    else if (form == TV_DERIVE_UP_WGRAD_FOLD && accumulate)
+        hipLaunchKernelGGL((tapsum_kernel<float, true, true>), grid, dim3(256), 0, s, src, (float*)dst, tab, A, Tin, Bd, stride);
+    else if (form == TV_DERIVE_UP_WGRAD_FOLD)
+        hipLaunchKernelGGL((tapsum_kernel<float, true, false>), grid, dim3(256), 0, s, src, (float*)dst, tab, A, Tin, Bd, stride);
+    else
+        hipLaunchKernelGGL((tapsum_kernel<bf16, true, false>), grid, dim3(256), 0, s, src, (bf16*)dst, tab, A, Tin, Bd, stride);
+    TV_CHECK_LAUNCH("tv_conv3x3_derived");
     return TV_OK;
 }
 

@@ -19,6 +19,7 @@ SO_PATH = os.environ.get("TV_HIP_SO") or os.path.join(_HERE, "libtransvae_hip.so
 
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 ACT_DERIV, ACT_SAVE_DERIV = 3, 16   # include/transvae_hip.h: saved tensor = act'(pre-activation)
+DERIVE_UP_FWD, DERIVE_UP_DGRAD, DERIVE_UP_WGRAD_FOLD, DERIVE_S2_PARITY = 1, 2, 3, 4   # tv_conv3x3_derived forms
 
 
 class ConvDesc(C.Structure):
@@ -45,6 +46,7 @@ SIGNATURES = {
     "tv_wgrad_tn_overwrites": (_I, [_DP]),
     "tv_wgrad_tn_acc": (_I, [_DP, _P, _P, _P, _P, _P]),
     "tv_pack_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "tv_conv3x3_derived": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "tv_gn_partial_count": (_LL, [_I, _I, _I]),
     "tv_gn_stats": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "tv_gn_silu_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

@@ -181,11 +181,14 @@ def _wg(ctx, iw, ib, geo, w, x, gz):
     need_w, need_b = ctx.needs_input_grad[iw], ctx.needs_input_grad[ib]
     if not (need_w or need_b):
         return None, None
-    if need_w and geo.mode not in ("shuf", "c3up"):
+    if need_w and geo.mode != "shuf":
         gp = getattr(ctx, "gparams", None)
         views = ops.grad_views(gp.get(iw), w, gp.get(ib), need_b) if gp else None
         if views is not None:      # micro-batch >= 2 of a step: add straight into param.grad, nothing for autograd to do
-            ops.wgrad_acc(geo.fwd_desc(0), x, gz, views[0], views[1])
+            if geo.mode == "c3up":
+                conv_wgrad(geo, w, x, gz, need_b, out=views, accumulate=True)
+            else:
+                ops.wgrad_acc(geo.fwd_desc(0), x, gz, views[0], views[1])
             ops.acc_stats["in_place"] += 1
             return None, None
         ops.acc_stats["autograd"] += 1

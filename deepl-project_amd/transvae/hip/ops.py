@@ -302,6 +302,7 @@ def wgrad_plan_desc(desc: L.ConvDesc, x, gy) -> L.ConvDesc:
 # Functions then add their weight / bias gradients straight into `param.grad` and hand autograd nothing to accumulate.
 _accum_grads = False
 acc_stats = {"in_place": 0, "autograd": 0}     # weight gradients added in place / handed to autograd (diagnostics, tests)
+in_place_params = set()    # id(parameter) of every weight / bias a kernel has added into in place (transvae.parallel reads it)
 
 
 @contextlib.contextmanager
@@ -345,6 +346,9 @@ def grad_views(pw, w: torch.Tensor, pb, need_b: bool):
             print("[transvae.hip] in-place accumulation skipped:", why, tuple(w.shape), flush=True)
         return None
     dw = gw.as_strided(tuple(w.shape), tuple(w.stride()), gw.storage_offset() + off)
+    in_place_params.add(id(pw))
+    if need_b:
+        in_place_params.add(id(pb))
     return dw, (pb.grad if need_b else None)
 
 
@@ -490,20 +494,16 @@ def _igemm_bwd(desc, gz, wt, residual, aux, aux_act, dx):
 _UP_SETS = (((0,), (1, 2)), ((0, 1), (2,)))
 
 
+def _derive(w: torch.Tensor, form: int, Cout: int, Cin: int, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """One tv_conv3x3_derived launch (csrc/elementwise.hip: tapsum_kernel); w fp32 contiguous in its [*, taps, *] layout."""
+    _require(w.dtype == torch.float32 and w.is_contiguous() and out.is_contiguous(), "derived operand needs contiguous fp32 input")
+    L.check(L.load().tv_conv3x3_derived(_p(w), _p(out), form, Cout, Cin, int(accumulate), _stream()), "tv_conv3x3_derived")
+    return out
+
+
 def _up_fwd_weight(w: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
     """Forward operand: bf16 [4*Cout, 2, 2, Cin], row (2*py+px)*Cout + co, tap (ty, tx)."""
-    w4 = w.view(Cout, 3, 3, Cin)
-    wf = torch.empty((4, Cout, 2, 2, Cin), dtype=torch.float32, device=w.device)
-    for py in (0, 1):
-        for px in (0, 1):
-            for ty in (0, 1):
-                for tx in (0, 1):
-                    acc = None
-                    for ky in _UP_SETS[py][ty]:
-                        for kx in _UP_SETS[px][tx]:
-                            acc = w4[:, ky, kx, :] if acc is None else acc + w4[:, ky, kx, :]
-                    wf[2 * py + px, :, ty, tx, :] = acc
-    return wf.to(BF16).view(4 * Cout, 2, 2, Cin)
+    return _derive(w.view(Cout, 3, 3, Cin), L.DERIVE_UP_FWD, Cout, Cin, torch.empty((4 * Cout, 2, 2, Cin), dtype=BF16, device=w.device))
 
 
 # The adjoint is a 4x4 / stride-2 / pad-1 convolution of the high-resolution gradient: input row r receives output rows
@@ -513,47 +513,23 @@ _UP_ADJ = ((2,), (1, 2), (0, 1), (0,))
 
 def _up_dgrad_weight(w: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
     """Data-gradient operand: bf16 [Cin, 4, 4, Cout]."""
-    w4 = w.view(Cout, 3, 3, Cin)
-    wd = torch.empty((Cin, 4, 4, Cout), dtype=torch.float32, device=w.device)
-    for ty in range(4):
-        for tx in range(4):
-            acc = None
-            for ky in _UP_ADJ[ty]:
-                for kx in _UP_ADJ[tx]:
-                    acc = w4[:, ky, kx, :] if acc is None else acc + w4[:, ky, kx, :]
-            wd[:, ty, tx, :] = acc.t()
-    return wd.to(BF16)
+    return _derive(w.view(Cout, 3, 3, Cin), L.DERIVE_UP_DGRAD, Cout, Cin, torch.empty((Cin, 4, 4, Cout), dtype=BF16, device=w.device))
 
 
-def _up_fold_wgrad(d16: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
+def _up_fold_wgrad(d16: torch.Tensor, Cout: int, Cin: int, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
     """[Cin, 4, 4, Cout] gradient of the 4x4 adjoint operand -> [Cout, 3, 3, Cin] gradient of the 3x3 weight
-    (tap t of the adjoint contains w[ky] for ky in _UP_ADJ[t], so dw[ky] sums the taps that contain it)."""
-    taps = tuple(tuple(t for t in range(4) if k in _UP_ADJ[t]) for k in range(3))   # ((2,3), (1,2), (0,1))
-    dw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=d16.device)
-    for ky in range(3):
-        for kx in range(3):
-            acc = None
-            for ty in taps[ky]:
-                for tx in taps[kx]:
-                    acc = d16[:, ty, tx, :] if acc is None else acc + d16[:, ty, tx, :]
-            dw[:, ky, kx, :] = acc.t()
-    return dw
+    (tap t of the adjoint contains w[ky] for ky in _UP_ADJ[t], so dw[ky] sums the taps that contain it: ((2,3), (1,2), (0,1))).
+    out + accumulate: add into an existing gradient buffer (in-place accumulation over micro-batches)."""
+    if out is None:
+        out = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=d16.device)
+    return _derive(d16, L.DERIVE_UP_WGRAD_FOLD, Cout, Cin, out, accumulate)
 
 
 def _s2_parity_weight(w: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
     """Data-gradient operand of a 3x3 / stride-2 / pad-1 convolution, by output parity (see conv_dgrad):
     bf16 [4*Cin, 2, 2, Cout];  row (2*py+px)*Cin + ci, tap (ty, tx) holds w[:, ky, kx, ci] with ky = 1 for py = 0 and
     ky = 2, 0 for ty = 0, 1 when py = 1 (kx likewise); taps outside the class's footprint stay zero."""
-    w4 = w.view(Cout, 3, 3, Cin)
-    wd = torch.zeros((4, Cin, 2, 2, Cout), dtype=torch.float32, device=w.device)
-    for py in (0, 1):
-        for px in (0, 1):
-            for ty in range(py + 1):
-                for tx in range(px + 1):
-                    ky = 1 if py == 0 else (2 if ty == 0 else 0)
-                    kx = 1 if px == 0 else (2 if tx == 0 else 0)
-                    wd[2 * py + px, :, ty, tx, :] = w4[:, ky, kx, :].t()
-    return wd.to(BF16).view(4 * Cin, 2, 2, Cout)
+    return _derive(w.view(Cout, 3, 3, Cin), L.DERIVE_S2_PARITY, Cout, Cin, torch.empty((4 * Cin, 2, 2, Cout), dtype=BF16, device=w.device))
 
 
 def conv_dgrad(g: _Geo, w, gz, x_shape, residual=None, aux=None, aux_act: int = 0):
@@ -623,8 +599,9 @@ def _wgrad_overwrites(desc: L.ConvDesc) -> bool:
 # out of a pre-zeroed slab: a backward pass asked for ~770 of them per micro-batch, each a separate ~5 us fill kernel on a
 # GPU that is otherwise saturated (profiles/: FillFunctor 0.7 % of the step).  A region is handed out once and never reused;
 # the slab lives as long as any tensor carved from it.
-_ZERO_SLAB_BYTES = 32 << 20
-_ZERO_SMALL_BYTES = 1 << 20
+_ZERO_SLAB_BYTES = 256 << 20
+_ZERO_SMALL_BYTES = 40 << 20       # (round 4: up to the largest weight gradient, 6144 x 1536 fp32 = 36 MiB -- the ~150 split-K
+                                   # gradient buffers of a step's first micro-batch were a fill kernel each)
 _zero_slabs = {}     # (device, stream) -> [slab tensor (uint8), offset]
 
 
@@ -662,8 +639,9 @@ def conv_wgrad_alloc(g: _Geo, w, need_db: bool, x=None, gz=None):
     return _grad_buffer(tuple(w.shape), w.device, zero), db
 
 
-def conv_wgrad(g: _Geo, w, x, gz, need_db: bool, out=None):
-    """(dw in w's layout, dbias | None), fp32.  `out` = buffers from conv_wgrad_alloc (optional)."""
+def conv_wgrad(g: _Geo, w, x, gz, need_db: bool, out=None, accumulate: bool = False):
+    """(dw in w's layout, dbias | None), fp32.  `out` = buffers from conv_wgrad_alloc (optional).
+    accumulate ('c3up' only, with out = (dw, dbias | None) holding the gradients of earlier micro-batches): add in place."""
     dev = x.device
     if g.mode == "c3up":
         # weight gradient of the polyphase form = that of its adjoint conv (gathered operand: the high-resolution
@@ -672,8 +650,13 @@ def conv_wgrad(g: _Geo, w, x, gz, need_db: bool, out=None):
                   kh=4, kw=4, stride=2, pad=1)
         d16 = _grad_buffer((g.Cin, 4, 4, g.Cout), dev, not _wgrad_overwrites(wgrad_plan_desc(d, gz, x)))
         wgrad(d, gz, x, d16, None)
-        dw = _up_fold_wgrad(d16, g.Cout, g.Cin)
         db = gz.view(-1, g.Cout).sum(0, dtype=torch.float32) if need_db else None
+        if accumulate:
+            _up_fold_wgrad(d16, g.Cout, g.Cin, out=out[0], accumulate=True)
+            if need_db:
+                out[1].add_(db)
+            return out
+        dw = _up_fold_wgrad(d16, g.Cout, g.Cin)
         return dw, db
     if out is not None and g.mode != "shuf":
         dw, db = out

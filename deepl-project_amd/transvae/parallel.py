@@ -157,6 +157,46 @@ def _accumulate_in_place(x: torch.Tensor, on: bool):
     return contextlib.nullcontext()
 
 
+_NO_SWAP = __import__("os").environ.get("TV_NO_GRAD_SWAP") == "1"      # A/B hook (bench.py --allow-tuning-env)
+swap_stats = {"micro_batches": 0, "tensors": 0}     # diagnostics (tests): micro-batches that ran with swapped accumulators
+
+
+def _swap_out_autograd_grads(params, x: torch.Tensor, in_place: bool):
+    """On an in-place micro-batch the kernels add the weight / bias gradients of the GEMM-shaped layers straight into
+    `param.grad`; every OTHER parameter (norm affines, folded projections, DC weights, ...: ~430 tensors of Large) still gets
+    its gradient from autograd, whose AccumulateGrad node launches one small add per tensor and micro-batch (1282 launches
+    per optimizer step, tools/probes/launch_census.py).  Instead: take those accumulators out (`grad = None`, so autograd
+    simply STORES this micro-batch's gradient) and add all of them back with one multi-tensor add afterwards.  Which
+    parameters the kernels handle is learned from the kernels themselves (ops.in_place_params, filled during the first
+    in-place micro-batch of the process, which therefore still runs the old way)."""
+    if not (in_place and x.is_cuda) or _NO_SWAP:
+        return None
+    from .hip import ops
+    known = ops.in_place_params
+    if not known:
+        return None
+    swapped = [(p, p.grad) for p in params if p.grad is not None and id(p) not in known]
+    for p, _ in swapped:
+        p.grad = None
+    swap_stats["micro_batches"] += 1
+    swap_stats["tensors"] += len(swapped)
+    return swapped
+
+
+def _swap_in_and_add(swapped):
+    if not swapped:
+        return
+    acc, new = [], []
+    for p, g0 in swapped:
+        g1 = p.grad
+        p.grad = g0
+        if g1 is not None:
+            acc.append(g0)
+            new.append(g1 if g1.dtype == g0.dtype else g1.to(g0.dtype))
+    if acc:
+        torch._foreach_add_(acc, new)
+
+
 def _packed_weight_cache(x: torch.Tensor):
     """The weights do not change between the micro-batches of a step: keep their bf16 repacks (HIP path only)."""
     if x.is_cuda:
@@ -240,15 +280,19 @@ def train_step(ddp_model: nn.Module, optimizer: torch.optim.Optimizer, x_local: 
     chunks = micro_batches(n_local, micro)
     total = torch.zeros((), device=x_local.device, dtype=torch.float32)
     optimizer.zero_grad(set_to_none=True)
+    params = list(ddp_model.parameters())
     with _packed_weight_cache(x_local):
         for i, (s, c) in enumerate(chunks):
             last = i == len(chunks) - 1
             sync_ctx = contextlib.nullcontext() if (last or not hasattr(ddp_model, "no_sync")) else ddp_model.no_sync()
             # in-place accumulation hands autograd no gradient for those parameters, so DDP's hooks would not fire: never on
             # the micro-batch that synchronises (also with ONE rank when the model is DDP-wrapped: wrap_ddp(force=True))
-            with sync_ctx, _accumulate_in_place(x_local, i > 0 and (not hasattr(ddp_model, "no_sync") or not last)):
+            in_place = i > 0 and (not hasattr(ddp_model, "no_sync") or not last)
+            swapped = _swap_out_autograd_grads(params, x_local, in_place)
+            with sync_ctx, _accumulate_in_place(x_local, in_place):
                 loss = forward_loss(ddp_model, x_local[s:s + c]) * (c * world / global_batch)
                 loss.backward()
+            _swap_in_and_add(swapped)
             total += loss.detach()
-    clip_and_step(list(ddp_model.parameters()), optimizer, grad_clip, counters)
+    clip_and_step(params, optimizer, grad_clip, counters)
     return total

@@ -136,6 +136,21 @@ int tv_wgrad_tn_acc(const tv_conv_desc* d, const void* x, const void* gy, float*
 int tv_pack_weight(const float* src, void* dst, void* dst_t, int O, int T, int I, int flip_taps,
                    void* stream);
 
+/* Operands DERIVED from a 3x3 weight by sums of taps, one launch each (replaces ~20-60 slice adds / copies of the host code):
+ *   TV_DERIVE_UP_FWD         w fp32 [Cout,3,3,Cin] -> bf16 [4*Cout,2,2,Cin]: nn.Upsample(nearest, 2) + 3x3 conv
+ *                            (R/transvae/modules/upsample.py:94-95) in polyphase form, row (2*py+px)*Cout + co, tap (ty,tx)
+ *   TV_DERIVE_UP_DGRAD       w -> bf16 [Cin,4,4,Cout]: its adjoint, a 4x4 / stride-2 / pad-1 convolution of the high-resolution gradient
+ *   TV_DERIVE_UP_WGRAD_FOLD  fp32 [Cin,4,4,Cout] (weight gradient of that adjoint) -> fp32 [Cout,3,3,Cin] (gradient of w);
+ *                            accumulate != 0 adds into dst (gradient accumulation over micro-batches)
+ *   TV_DERIVE_S2_PARITY      w -> bf16 [4*Cin,2,2,Cout]: data-gradient operand of the 3x3 / stride-2 convolution by output parity
+ *                            (R/transvae/modules/upsample.py:33-37), taps outside a class's footprint zero
+ * Sums are taken in fp32 in a fixed order (ky outer, kx inner) and rounded once. */
+#define TV_DERIVE_UP_FWD 1
+#define TV_DERIVE_UP_DGRAD 2
+#define TV_DERIVE_UP_WGRAD_FOLD 3
+#define TV_DERIVE_S2_PARITY 4
+int tv_conv3x3_derived(const float* src, void* dst, int form, int c_out, int c_in, int accumulate, void* stream);
+
 /* GroupNorm(32)+SiLU (R/transvae/modules/blocks.py:33,36,60-65; decoder.py:93,128-129) --------- */
 /* Reductions over all pixels of an image span workgroups: each block writes a partial sum and a
  * finalize kernel adds the partials in block order (no atomics => bit-reproducible).  `partials`

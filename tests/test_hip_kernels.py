@@ -931,3 +931,60 @@ def test_shuffled_store_register_forms_are_bit_identical_to_the_lds_loop(B, H):
     for k in reg:
         assert torch.isfinite(reg[k].float()).all(), k
         assert torch.equal(reg[k], lds[k]), (k, float((reg[k].float() - lds[k].float()).abs().max()))
+
+
+# ---- operands derived from a 3x3 weight in one launch (tv_conv3x3_derived) against the slice algebra they replace -----------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cout,Cin", [(64, 32), (192, 384), (40, 72), (768, 1536)])
+def test_derived_3x3_operands_equal_the_slice_algebra(Cout, Cin):
+    """Polyphase forward operand, its 4x4 adjoint operand, the fold of the adjoint's weight gradient back onto the nine taps
+    (plain and accumulating) and the parity operand of the stride-2 data gradient: bit-identical to the chain of slice adds /
+    transposes / casts of torch that transvae/hip/ops.py ran before round 4 (~20-60 launches each)."""
+    from transvae.hip import ops
+    UP_SETS = (((0,), (1, 2)), ((0, 1), (2,)))
+    UP_ADJ = ((2,), (1, 2), (0, 1), (0,))
+    g = torch.Generator(device=dev()).manual_seed(Cout * 7 + Cin)
+    w = torch.randn(Cout, 3, 3, Cin, device=dev(), generator=g) * (9 * Cin) ** -0.5
+
+    def tapsum(sets_y, sets_x, src=w):
+        acc = None
+        for ky in sets_y:
+            for kx in sets_x:
+                acc = src[:, ky, kx, :] if acc is None else acc + src[:, ky, kx, :]
+        return acc
+    # forward operand
+    wf = torch.empty((4, Cout, 2, 2, Cin), dtype=torch.float32, device=dev())
+    for py in (0, 1):
+        for px in (0, 1):
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    wf[2 * py + px, :, ty, tx, :] = tapsum(UP_SETS[py][ty], UP_SETS[px][tx])
+    assert torch.equal(ops._up_fwd_weight(w, Cout, Cin), wf.to(BF).view(4 * Cout, 2, 2, Cin))
+    # adjoint operand
+    wd = torch.empty((Cin, 4, 4, Cout), dtype=torch.float32, device=dev())
+    for ty in range(4):
+        for tx in range(4):
+            wd[:, ty, tx, :] = tapsum(UP_ADJ[ty], UP_ADJ[tx]).t()
+    assert torch.equal(ops._up_dgrad_weight(w, Cout, Cin), wd.to(BF))
+    # fold of the adjoint's weight gradient
+    d16 = torch.randn(Cin, 4, 4, Cout, device=dev(), generator=g)
+    taps = tuple(tuple(t for t in range(4) if k in UP_ADJ[t]) for k in range(3))
+    dw = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=dev())
+    for ky in range(3):
+        for kx in range(3):
+            dw[:, ky, kx, :] = tapsum(taps[ky], taps[kx], d16).t()
+    assert torch.equal(ops._up_fold_wgrad(d16, Cout, Cin), dw)
+    acc0 = torch.randn(Cout, 3, 3, Cin, device=dev(), generator=g)
+    acc = acc0.clone()
+    ops._up_fold_wgrad(d16, Cout, Cin, out=acc, accumulate=True)
+    assert torch.equal(acc, acc0 + dw)
+    # parity operand of the stride-2 data gradient
+    wp = torch.zeros((4, Cin, 2, 2, Cout), dtype=torch.float32, device=dev())
+    for py in (0, 1):
+        for px in (0, 1):
+            for ty in range(py + 1):
+                for tx in range(px + 1):
+                    ky = 1 if py == 0 else (2 if ty == 0 else 0)
+                    kx = 1 if px == 0 else (2 if tx == 0 else 0)
+                    wp[2 * py + px, :, ty, tx, :] = w[:, ky, kx, :].t()
+    assert torch.equal(ops._s2_parity_weight(w, Cout, Cin), wp.to(BF).view(4 * Cin, 2, 2, Cout))

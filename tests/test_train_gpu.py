@@ -148,6 +148,49 @@ def test_in_place_gradient_accumulation_equals_autograd_accumulation():
     assert per_mb[0]["in_place"] == 0 and per_mb[1]["in_place"] > per_mb[1]["autograd"] and per_mb[2] == per_mb[1]
 
 
+def test_train_step_micro_batches_equal_one_batch_and_accumulators_are_swapped():
+    """transvae.parallel.train_step over four micro-batches of one image: the kernels add the GEMM layers' gradients in place,
+    every other parameter's accumulator is taken out for the backward pass and added back by ONE multi-tensor add
+    (parallel._swap_out_autograd_grads) -- the gradients equal those of the same four images in one micro-batch (fp32
+    summation order), for two consecutive steps (the first in-place micro-batch of a process still runs the old way and
+    teaches which parameters the kernels own)."""
+    from transvae import parallel
+    from transvae.hip import ops
+    from transvae.parallel import train_step, vae_bench_loss
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(4, 3, 64, 64, generator=g).to(DEV)
+    eps = torch.randn(4, 4, 4, 4, generator=g).to(DEV)
+    res = {}
+    for micro in (4, 1):
+        m = micro_model(clamp_latent=True)
+        m.train()
+        opt = torch.optim.SGD(m.parameters(), lr=0.0)        # the parameters stay put: both steps see the same gradients
+        cursor = [0]
+
+        def forward_loss(model, xb):
+            e = eps[cursor[0]:cursor[0] + xb.shape[0]]
+            cursor[0] += xb.shape[0]
+            recon, mu, logvar = model(xb, eps=e)
+            return vae_bench_loss(recon, xb, mu, logvar)
+        before = dict(parallel.swap_stats)
+        out = []
+        for _ in range(2):
+            cursor[0] = 0
+            loss = train_step(m, opt, x, micro, forward_loss, None, 4, {})
+            out.append((float(loss), {k: p.grad.detach().double().cpu() for k, p in m.named_parameters()}))
+        res[micro] = out
+        if micro == 1:
+            engaged = parallel.swap_stats["micro_batches"] - before["micro_batches"]
+            tensors = parallel.swap_stats["tensors"] - before["tensors"]
+            print("micro-batches with swapped accumulators:", engaged, " tensors swapped:", tensors, " parameters the kernels own:", len(ops.in_place_params))
+            assert engaged >= 5 and tensors > 0 and len(ops.in_place_params) > 20       # (6 in-place micro-batches; the very first may teach)
+    for step in range(2):
+        assert abs(res[1][step][0] - res[4][step][0]) < 1e-6 * abs(res[4][step][0])
+        for k, a in res[4][step][1].items():
+            b = res[1][step][1][k]
+            assert float((a - b).norm()) <= 2e-5 * float(a.norm()) + 1e-9, (step, k, float((a - b).norm()), float(a.norm()))
+
+
 def test_large_two_train_steps_against_the_reference(golden_dir):
     """The metric's unit of work pinned to the reference at the headline configuration: TWO optimizer steps of TransVAE-Large
     f16d32 (one 256 x 256 image per step) through transvae.parallel.train_step + transvae.optim.FusedAdamW -- the patched

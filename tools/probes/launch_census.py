@@ -27,7 +27,7 @@ for _ in range(2):
     train_step(m, opt, x, 1, forward_loss, 1.0, 4, counters)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     train_step(m, opt, x, 1, forward_loss, 1.0, 4, counters)
     torch.cuda.synchronize()
 kern = collections.Counter()
@@ -47,6 +47,13 @@ for e in prof.events():
         st = [s for s in (e.stack or []) if "deepl-project_amd" in s or "parallel.py" in s]
         where = st[0].split("deepl-project_amd/")[-1] if st else ("autograd engine / other" )
         ops_[(e.name, where[:110])] += 1
+shp = collections.Counter()
+for e in prof.events():
+    if e.device_type == torch.autograd.DeviceType.CPU and e.name in ("aten::zero_", "aten::fill_", "aten::add_", "aten::add", "aten::copy_", "aten::mul", "aten::clone", "aten::cat", "aten::sum"):
+        shp[(e.name, str(e.input_shapes)[:90])] += 1
+print("aten ops by input shapes:")
+for (n, sh), c in shp.most_common(70):
+    print(f"  {c:5d} {n:12s} {sh}")
 print("aten ops by nearest repo frame:")
 for (n, s), c in ops_.most_common(45):
     print(f"  {c:5d} {n:18s} {s}")
