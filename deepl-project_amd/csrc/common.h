@@ -58,7 +58,12 @@ struct TvPerDeviceOnce {
 #define TV_ACT_NONE 0
 #define TV_ACT_GELU 1
 #define TV_ACT_SILU 2
+#ifndef TV_ACT_DERIV
 #define TV_ACT_DERIV 3        // (aux_act only) the saved tensor already holds act'(pre-activation)
+#endif
+#ifndef TV_ACT_ADD
+#define TV_ACT_ADD 4          // (aux_act only) the second tensor is added: out = acc + residual + aux
+#endif
 #define TV_ACT_SAVE_DERIV 16  // (flag on desc.act) pre_act receives act'(pre-activation) instead of the pre-activation
 
 __device__ __forceinline__ float tv_fast_exp(float x) { return __expf(x); }

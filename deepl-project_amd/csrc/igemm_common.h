@@ -229,7 +229,8 @@ enum { EF_GENERIC = 0, EF_PLAIN = 1, EF_GELU_D = 2, EF_SILU_D = 3, EF_GELU = 4, 
        EF_ROPE = 9,        // QKV projection with the RoPE rotation of its q / k columns
        // register forms with a SHUFFLED store (round 3): pixel-shuffle (store_shuffle 1: DC paths, parity data gradient of the
        // stride-2 convolutions) and the phase-shuffled store of the polyphase upsampling convolution (store_shuffle 2)
-       EF_PLAIN_S1 = 10, EF_RES_S1 = 11, EF_DERIV_S1 = 12, EF_SILU_D_S2 = 13, EF_PLAIN_S2 = 14 };
+       EF_PLAIN_S1 = 10, EF_RES_S1 = 11, EF_DERIV_S1 = 12, EF_SILU_D_S2 = 13, EF_PLAIN_S2 = 14,
+       EF_RES2 = 15 };     // acc + residual + second residual (TV_ACT_ADD): two branch values join the stream in one fp32 sum
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void epi_pair_exchange(bf16x8& a, bf16x8& b) {   // an involution: lanes fi < 8 keep a, lanes fi >= 8 keep b
@@ -306,6 +307,9 @@ __device__ __forceinline__ bf16x8 epi_math(float (&v)[8], const bf16x8& ld, cons
     if constexpr (FORM == EF_RES_DERIV) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (v[e] + (float)ld[e]) * (float)ld2[e];
+    } else if constexpr (FORM == EF_RES2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)ld2[e] + (float)ld[e];     // (branch values first, the stream last)
     } else if constexpr (FORM == EF_RES) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += (float)ld[e];
@@ -376,8 +380,8 @@ __device__ __forceinline__ void epilogue_direct(const IgemmArgs& p, const f32x4 
                                                 int lane, int nw0, RowMap m_of_row) {
     constexpr int MF = WTM / 16, NF = WTN / 16, NC = NF / 2;
     static_assert(NF % 2 == 0, "a lane's channels must come in whole 8-channel chunks");
-    constexpr bool LOADS = FORM == EF_RES || FORM == EF_DERIV || FORM == EF_RES_DERIV;
-    constexpr bool LOADS2 = FORM == EF_RES_DERIV;
+    constexpr bool LOADS = FORM == EF_RES || FORM == EF_DERIV || FORM == EF_RES_DERIV || FORM == EF_RES2;
+    constexpr bool LOADS2 = FORM == EF_RES_DERIV || FORM == EF_RES2;
     constexpr bool SAVES = FORM == EF_GELU_D || FORM == EF_SILU_D;
     // fragment rows per batch: the loads of a whole batch are issued before its arithmetic (their latency runs once per
     // batch, not once per line; one load per line in flight measured 0.96-0.99x of the LDS form, which batches them)
@@ -729,7 +733,10 @@ __device__ __forceinline__ void epilogue_lds(const IgemmArgs& p, const f32x4 (&a
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
                 }
-                if (p.aux_act == TV_ACT_DERIV) {
+                if (p.aux_act == TV_ACT_ADD) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)av[e];
+                } else if (p.aux_act == TV_ACT_DERIV) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= (float)av[e];
                 } else {
@@ -779,6 +786,7 @@ __device__ __forceinline__ void epilogue(const IgemmArgs& p, const f32x4 (&acc)[
                 case EF_GELU: epilogue_direct<WTM, WTN, EF_GELU>(p, acc, bv, lane, nw0, m_of_row); return;
                 case EF_SILU: epilogue_direct<WTM, WTN, EF_SILU>(p, acc, bv, lane, nw0, m_of_row); return;
                 case EF_RES_DERIV: epilogue_direct<WTM, WTN, EF_RES_DERIV>(p, acc, bv, lane, nw0, m_of_row); return;
+                case EF_RES2: epilogue_direct<WTM, WTN, EF_RES2>(p, acc, bv, lane, nw0, m_of_row); return;
                 case EF_ROPE: epilogue_direct<WTM, WTN, EF_ROPE>(p, acc, bv, lane, nw0, m_of_row); return;
                 case EF_PLAIN_S1: epilogue_direct<WTM, WTN, EF_PLAIN, 1>(p, acc, bv, lane, nw0, m_of_row); return;
                 case EF_RES_S1: epilogue_direct<WTM, WTN, EF_RES, 1>(p, acc, bv, lane, nw0, m_of_row); return;

@@ -946,7 +946,10 @@ int epilogue_form(const IgemmArgs& a) {
         return a.act == TV_ACT_NONE ? EF_PLAIN_S2 : EF_GENERIC;
     }
     if (a.rope) return (!a.aux && !a.res && !a.pre && a.act == TV_ACT_NONE && a.rope_cols % 32 == 0) ? EF_ROPE : EF_GENERIC;
-    if (a.aux) return (a.res && a.aux_act == TV_ACT_DERIV && !a.pre && a.act == TV_ACT_NONE) ? EF_RES_DERIV : EF_GENERIC;
+    if (a.aux) {
+        if (!a.res || a.pre || a.act != TV_ACT_NONE) return EF_GENERIC;
+        return a.aux_act == TV_ACT_DERIV ? EF_RES_DERIV : (a.aux_act == TV_ACT_ADD ? EF_RES2 : EF_GENERIC);
+    }
     if (a.res) return EF_GENERIC;
     if (a.pre) {
         if (!a.pre_deriv) return EF_GENERIC;
@@ -1195,7 +1198,7 @@ extern "C" int tv_igemm_nt(const tv_conv_desc* d, const void* x, const void* w, 
 
 extern "C" int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const void* w, const void* residual,
                                    const void* aux_pre_act, int aux_act, void* out, void* stream) {
-    TV_CHECK_ARG(aux_pre_act && aux_act >= 0 && aux_act <= TV_ACT_DERIV && d && d->act == TV_ACT_NONE,
+    TV_CHECK_ARG(aux_pre_act && aux_act >= 0 && aux_act <= TV_ACT_ADD && d && d->act == TV_ACT_NONE,
                  "tv_igemm_nt_actgrad: needs the saved pre-activation, a valid activation id and desc.act == NONE");
     return igemm_nt_impl(d, x, w, nullptr, residual, nullptr, out, aux_pre_act, aux_act, stream);
 }

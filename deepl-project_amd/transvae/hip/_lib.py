@@ -19,6 +19,7 @@ SO_PATH = os.environ.get("TV_HIP_SO") or os.path.join(_HERE, "libtransvae_hip.so
 
 ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
 ACT_DERIV, ACT_SAVE_DERIV = 3, 16   # include/transvae_hip.h: saved tensor = act'(pre-activation)
+ACT_ADD = 4                         # aux_act of tv_igemm_nt_actgrad: out = conv + residual + aux (a second residual)
 DERIVE_UP_FWD, DERIVE_UP_DGRAD, DERIVE_UP_WGRAD_FOLD, DERIVE_S2_PARITY = 1, 2, 3, 4   # tv_conv3x3_derived forms
 
 

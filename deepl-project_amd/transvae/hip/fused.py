@@ -309,6 +309,7 @@ class AttnBranchFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------
 # Conv-FFN branch:  t + W_out (u + W3 gelu(K3x3 gelu(W1 u))) ,  u = gelu(W_in RMS-hat(t))
+# The tail runs in collapsed form (ops.ffn_collapsed_operands):  t + W_out u + (W_out W3) c2 + (W_out b3 + b_out).
 # ------------------------------------------------------------------------------------------------
 class ConvFFNBranchFn(torch.autograd.Function):
     @staticmethod
@@ -316,43 +317,78 @@ class ConvFFNBranchFn(torch.autograd.Function):
         ops._need_gpu(t)
         T, d = t.shape
         train = any(ctx.needs_input_grad)
+        b3, b_out = _c(b3), _c(b_out)
         r = rownorm_fwd(t, None, 0, eps_rms, 1e-5)
         u, pre_u, geo_in, w_in_c = conv_forward(r, w_in, _c(b_in), None, "linear", GELU, train and _WANT)
         c1, pre_c1, geo1, w1c = conv_forward(u, w1, _c(b1), None, "linear", GELU, train and _WANT)
         mid = c1.shape[1]
         c2, pre_c2, geo2, w2c = conv_forward(c1.view(B, H, W, mid), w2, _c(b2), None, "c3s1", GELU, train and _WANT)
-        u2, _, geo3, w3c = conv_forward(c2.view(T, mid), w3, _c(b3), u, "linear", NONE, False)
-        out, _, geo_out, w_out_c = conv_forward(u2, w_out, _c(b_out), t, "linear", NONE, False)
-        ctx.geo = (geo_in, geo1, geo2, geo3, geo_out)
+        w3c, w_out_c = w3.contiguous(), w_out.contiguous()
+        wc_f, wc_t, bc = ops.ffn_collapsed_operands(w_out_c, w3c, b3, b_out)
+        # the two branch values join the residual stream in ONE fp32 sum (TV_ACT_ADD): t itself is rounded once, as in
+        # the reference's order of operations (an intermediate t + ... in bf16 would round the stream a second time)
+        o1 = ops.gemm_rows(c2.view(T, mid), wc_f, d, bias=bc)                           # (W_out W3) c2 + W_out b3 + b_out
+        wo_f, _ = ops.pack_weight(w_out_c.view(d, 1, w_out_c.shape[1]), True, False, False)
+        out = ops.gemm_rows(u, wo_f.view(d, -1), d, residual=t, aux=o1, aux_act=L.ACT_ADD)      # t + W_out u + o1
+        geo_out = ops._Geo("linear", u, w_out_c)
+        ctx.geo = (geo_in, geo1, geo2, geo_out)
         _stash(ctx, (1, w_in), (2, b_in), (3, w1), (4, b1), (5, w2), (6, b2), (7, w3), (8, b3), (9, w_out), (10, b_out))
         ctx.meta = (B, H, W, eps_rms)
-        ctx.save_for_backward(t, r, u, pre_u, c1, pre_c1, c2, pre_c2, u2, w_in_c, w1c, w2c, w3c, w_out_c)
+        ctx.save_for_backward(t, r, u, pre_u, c1, pre_c1, c2, pre_c2, w_in_c, w1c, w2c, w3c, w_out_c, wc_t, b3)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        t, r, u, pre_u, c1, pre_c1, c2, pre_c2, u2, w_in, w1, w2, w3, w_out = ctx.saved_tensors
-        geo_in, geo1, geo2, geo3, geo_out = ctx.geo
+        t, r, u, pre_u, c1, pre_c1, c2, pre_c2, w_in, w1, w2, w3, w_out, wc_t, b3 = ctx.saved_tensors
+        geo_in, geo1, geo2, geo_out = ctx.geo
         B, H, W, eps_rms = ctx.meta
         T, d = t.shape
         mid = c1.shape[1]
+        hid = u.shape[1]
         g = g.contiguous()
-        du2 = conv_dgrad(geo_out, w_out, g, u2.shape)                                   # [T,4d]
-        dw_out, db_out = _wg(ctx, 9, 10, geo_out, w_out, u2, g)
-        gz_c2 = conv_dgrad(geo3, w3, du2, (T, mid), aux=pre_c2.view(T, mid), aux_act=_aux_act(GELU))   # d/d pre_c2
-        dw3, db3 = _wg(ctx, 7, 8, geo3, w3, c2.view(T, mid), du2)
+        need = ctx.needs_input_grad
+        # d u = g W_out + gz_c1 W1 as ONE GEMM over K = d + mid (ops.ffn_du_operand): the operand rows are [g | gz_c1]
+        cat = torch.empty((T, d + mid), dtype=BF16, device=t.device)
+        cat[:, :d].copy_(g)
+        # ---- the composite: G = g^T c2 (+ sum_t g), then the chain rule onto W_out, W3, b3 (deferred while in-place)
+        gp = ctx.gparams
+        p_out, p3, pb3 = gp.get(9), gp.get(7), gp.get(8)
+        need_chain = need[7] or need[8] or need[9]
+        dw3 = db3 = dwo_chain = None
+        deferred = False
+        if need_chain:
+            views = ops.grad_views(p_out, w_out, gp.get(10), need[10]) if (need[9] and need[7] and p3 is not None) else None
+            dG = ops._rows_desc(T, mid, d)
+            if views is not None:       # in-place micro-batch: accumulate G and the column sums, chain rule at the end of the step
+                ent = ops.defer_ffn_grad(p_out, p3, pb3, w_out, w3, b3, need[8])
+                ops.wgrad_acc(dG, c2.view(T, mid), g, ent["G"], ent["gs"])
+                deferred = True
+            else:
+                pend = ops.take_deferred_ffn(p_out)           # (a syncing micro-batch after in-place ones: fold their share in)
+                G = pend["G"] if pend is not None else ops.zeros_f32((d, mid), t.device)
+                gs = pend["gs"] if pend is not None else ops.zeros_f32((d,), t.device)
+                ops.wgrad_acc(dG, c2.view(T, mid), g, G, gs)
+                dwo_chain, dw3, db3 = ops.ffn_chain_grads(G, gs if b3 is not None else None, w_out, w3, b3)
+        dw_out, db_out = _wg(ctx, 9, 10, geo_out, w_out, u, g)                          # direct part: g^T u, sum_t g
+        if dwo_chain is not None and need[9]:
+            dw_out = dwo_chain if dw_out is None else dw_out.add_(dwo_chain)
+        gz_c2 = ops.gemm_rows(g, wc_t, mid, aux=pre_c2.view(T, mid), aux_act=_aux_act(GELU))    # (g Wc) * gelu'(pre_c2)
         gz_c2 = gz_c2.view(B, H, W, mid)
         gz_c1 = conv_dgrad(geo2, w2, gz_c2, (B, H, W, mid), aux=pre_c1.view(B, H, W, mid), aux_act=_aux_act(GELU))
         dw2, db2 = _wg(ctx, 5, 6, geo2, w2, c1.view(B, H, W, mid), gz_c2)
         gz_c1 = gz_c1.view(T, mid)
-        gz_u = conv_dgrad(geo1, w1, gz_c1, u.shape, residual=du2, aux=pre_u, aux_act=_aux_act(GELU))   # (W1^T gz_c1 + du2) * gelu'(pre_u)
+        cat[:, d:].copy_(gz_c1)
+        gz_u = ops.gemm_rows(cat, ops.ffn_du_operand(w_out, w1), hid, aux=pre_u, aux_act=_aux_act(GELU))   # (g W_out + gz_c1 W1) * gelu'(pre_u)
+        del cat
         dw1, db1 = _wg(ctx, 3, 4, geo1, w1, u, gz_c1)
-        del du2
         dr = conv_dgrad(geo_in, w_in, gz_u, r.shape)
         dw_in, db_in = _wg(ctx, 1, 2, geo_in, w_in, r, gz_u)
         dt, _ = rownorm_bwd(t, None, dr, g, 0, eps_rms, 1e-5)                           # + residual gradient, fused
         _join(ctx, t.device)
-        return dt, dw_in, db_in, dw1, db1, dw2, db2, dw3, db3, dw_out, db_out, None, None, None, None
+        if deferred:
+            dw3 = db3 = None
+        return (dt, dw_in, db_in, dw1, db1, dw2, db2, dw3 if need[7] else None, db3 if need[8] else None,
+                dw_out if need[9] else None, db_out, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------

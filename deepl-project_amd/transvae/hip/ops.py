@@ -83,13 +83,16 @@ def packed_weight_cache():
 
     Only views of (or) nn.Parameters are cached, keyed on the parameter object and its version counter, so tensors
     computed per forward (LayerNorm-folded projections) are always repacked and an in-place update invalidates the
-    entry.  The cache lives for the duration of the block (transvae/parallel.py wraps the micro-batch loop)."""
+    entry.  The cache lives for the duration of the block (transvae/parallel.py wraps the micro-batch loop).
+    Gradients deferred by the collapsed Conv-FFN tail (see ffn_collapsed_operands) are flushed when the outermost block ends."""
     global _pack_cache
     prev, _pack_cache = _pack_cache, {}
     try:
         yield
     finally:
         _pack_cache = prev
+        if prev is None:
+            flush_deferred_grads()
 
 
 # ---- bf16 operands owned by transvae.optim.FusedAdamW -------------------------------------------------------------
@@ -313,6 +316,8 @@ def accumulate_grads_in_place(on: bool = True):
         yield
     finally:
         _accum_grads = prev
+        if _pack_cache is None:      # (inside a packed_weight_cache() block -- one optimizer step -- the flush waits for its end)
+            flush_deferred_grads()
 
 
 def param_of(t: Optional[torch.Tensor]):
@@ -323,9 +328,10 @@ def param_of(t: Optional[torch.Tensor]):
     return base if isinstance(base, torch.nn.Parameter) else None
 
 
-def grad_views(pw, w: torch.Tensor, pb, need_b: bool):
-    """(dw buffer laid out like `w` inside pw.grad, bias gradient buffer | None) when both can be accumulated in place."""
-    if not _accum_grads:
+def grad_views(pw, w: torch.Tensor, pb, need_b: bool, force: bool = False):
+    """(dw buffer laid out like `w` inside pw.grad, bias gradient buffer | None) when both can be accumulated in place.
+    force: also outside the in-place mode (the flush of deferred gradients adds into gradients that exist)."""
+    if not (_accum_grads or force):
         return None
     why = None
     if pw is None or pw.grad is None:
@@ -530,6 +536,165 @@ def _s2_parity_weight(w: torch.Tensor, Cout: int, Cin: int) -> torch.Tensor:
     bf16 [4*Cin, 2, 2, Cout];  row (2*py+px)*Cin + ci, tap (ty, tx) holds w[:, ky, kx, ci] with ky = 1 for py = 0 and
     ky = 2, 0 for ty = 0, 1 when py = 1 (kx likewise); taps outside the class's footprint stay zero."""
     return _derive(w.view(Cout, 3, 3, Cin), L.DERIVE_S2_PARITY, Cout, Cin, torch.empty((4 * Cin, 2, 2, Cout), dtype=BF16, device=w.device))
+
+
+# ---- Conv-FFN tail in collapsed form ---------------------------------------------------------------------------------------
+# R/transvae/modules/conv.py:85-104:  u <- u + W3 c + b3 ;  out = W_out u + b_out.  Nothing non-linear sits between the two
+# projections, so   out = W_out u + (W_out W3) c + (W_out b3 + b_out) :  the [T, 4d] tensor u + W3 c is never formed, the
+# d -> 4d GEMM (and, in the backward pass, its data gradient from the [T, 4d] gradient and its weight gradient) becomes a
+# d -> d GEMM on the composite  Wc = W_out W3  [d, mid]  (a quarter of the FLOPs, none of the [T, 4d] passes), and the chain
+# rule hands the composite's gradient  G = g^T c  [d, mid]  (g = d out) back to the parameters with two small products:
+#     dW_out += G W3^T      dW3 = W_out^T G      db3 = W_out^T sum_t g      db_out = sum_t g
+# Wc / bc are operands derived from parameters (built once per optimizer step inside a packed_weight_cache() block, like
+# the polyphase forms); G accumulates over the in-place micro-batches of a step and the two products run once, at its end
+# (flush_deferred_grads, called by transvae.parallel.train_step through the packed_weight_cache() block, and by
+# accumulate_grads_in_place() when no such block is open).  Outside the in-place mode the Function applies the chain rule
+# at once, so a plain loss.backward() / optimizer.step() loop (R/train.py:577-620) gets complete gradients.
+def _rows_desc(rows: int, c_in: int, c_out: int) -> L.ConvDesc:
+    return _desc(batch=rows, h_in=1, w_in=1, c_in=c_in, ldx=c_in, h_out=1, w_out=1, c_out=c_out, ldo=c_out, kh=1, kw=1)
+
+
+def gemm_rows(x: torch.Tensor, wb: torch.Tensor, c_out: int, bias=None, residual=None, aux=None, aux_act: int = 0) -> torch.Tensor:
+    """out[T, c_out] = x[T, K] wb[c_out, K]^T (+ bias) (+ residual) (x act'(aux)); wb is a packed bf16 operand."""
+    T, K = x.shape
+    out = torch.empty((T, c_out), dtype=BF16, device=x.device)
+    d = _rows_desc(T, K, c_out)
+    if aux is None:
+        igemm(d, x, wb, bias, residual, None, out)
+    else:
+        _require(bias is None, "gemm_rows: bias and a derivative multiply do not combine")
+        _igemm_bwd(d, x, wb, residual, aux, aux_act, out)
+    return out
+
+
+def ffn_collapsed_operands(w_out: torch.Tensor, w3: torch.Tensor, b3, b_out):
+    """(Wc bf16 [d, mid], Wc^T bf16 [mid, d], bc fp32 [d]) for w_out [d, hid], w3 [hid, mid] fp32 parameter views."""
+    d, hid = w_out.shape
+    mid = w3.shape[1]
+
+    def build():
+        wo_f, _ = pack_weight(w_out.view(d, 1, hid), True, False, False)        # bf16 [d, hid]
+        _, w3_t = pack_weight(w3.view(hid, 1, mid), False, True, False)         # bf16 [mid, hid]
+        wc_f = gemm_rows(wo_f.view(d, hid), w3_t.view(mid, hid), mid)           # Wc[o, j] = sum_h W_out[o, h] W3[h, j]
+        wc_t = gemm_rows(w3_t.view(mid, hid), wo_f.view(d, hid), d)             # its transpose (data-gradient operand)
+        if b3 is not None:
+            bc = torch.mv(w_out, b3) if b_out is None else torch.addmv(b_out, w_out, b3)
+        else:
+            bc = b_out
+        return wc_f, wc_t, (bc.contiguous() if bc is not None else None)
+    if _pack_cache is None:
+        return build()
+    bo, b3b = param_of(w_out), param_of(w3)
+    if bo is None or b3b is None:
+        return build()
+    key = ("ffn_collapsed", id(bo), bo._version, id(b3b), b3b._version, w_out.data_ptr(), w3.data_ptr(),
+           None if b3 is None else (b3.data_ptr(), b3._version), None if b_out is None else (b_out.data_ptr(), b_out._version))
+    hit = _pack_cache.get(key)
+    if hit is None:
+        hit = _pack_cache[key] = build()
+    return hit
+
+
+def ffn_du_operand(w_out: torch.Tensor, w1: torch.Tensor) -> torch.Tensor:
+    """bf16 [hid, d + mid] = [W_out^T | W1^T]: the operand of the ONE data-gradient GEMM onto u,
+    d u = [g | gz_c1] [W_out ; W1]  (K = d + mid), instead of g W_out written as a [T, 4d] tensor and read back as the
+    residual of gz_c1 W1.  Built from the optimizer-kept transposed forms; cached per step inside packed_weight_cache()."""
+    d, hid = w_out.shape
+    mid = w1.shape[0]
+
+    def build():
+        _, wo_t = pack_weight(w_out.view(d, 1, hid), False, True, False)        # bf16 [hid, 1, d]
+        _, w1_t = pack_weight(w1.view(mid, 1, hid), False, True, False)         # bf16 [hid, 1, mid]
+        return torch.cat([wo_t.view(hid, d), w1_t.view(hid, mid)], dim=1)
+    bo, b1 = param_of(w_out), param_of(w1)
+    if _pack_cache is None or bo is None or b1 is None:
+        return build()
+    key = ("ffn_du", id(bo), bo._version, id(b1), b1._version, w_out.data_ptr(), w1.data_ptr())
+    hit = _pack_cache.get(key)
+    if hit is None:
+        hit = _pack_cache[key] = build()
+    return hit
+
+
+def ffn_chain_grads(G: torch.Tensor, gs, w_out: torch.Tensor, w3: torch.Tensor, b3=None, out_w=None, out_w3=None):
+    """The composite's gradient back to the parameters: (dW_out chain part [d, hid], dW3 [hid, mid], db3 [hid] | None), fp32.
+    G fp32 [d, mid], gs = sum_t g fp32 [d] | None (with b3: the rank-one term  sum_t g (x) b3  of dW_out, and db3).
+    out_w / out_w3: gradient buffers to ADD into (in place) instead.  G enters the two products as a bf16 hi + lo pair
+    (G = bf16(G) + bf16(G - bf16(G)) to 2^-17): the products keep the precision of an fp32 gradient against bf16 weights."""
+    d, hid = w_out.shape
+    mid = w3.shape[1]
+    wo_f, _ = pack_weight(w_out.view(d, 1, hid), True, False, False)            # bf16 [d, hid]
+    _, w3_t = pack_weight(w3.view(hid, 1, mid), False, True, False)             # bf16 [mid, hid]
+    d1 = _rows_desc(mid, hid, d)     # dW_out[o, h] += sum_j G[o, j] W3[h, j]: over the mid "pixels" j, gy = G^T [mid, d], x = W3^T [mid, hid]
+    d2 = _rows_desc(d, mid, hid)     # dW3[h, j]     = sum_o W_out[o, h] G[o, j]: over the d "pixels" o, gy = W_out [d, hid], x = G [d, mid]
+    dwo = out_w if out_w is not None else zeros_f32((d, hid), G.device)
+    dw3 = out_w3 if out_w3 is not None else zeros_f32((hid, mid), G.device)
+    part = G
+    for _ in range(2):
+        Gb, GbT = pack_weight(part.view(d, 1, mid), True, True, False)           # bf16 [d, mid], [mid, d]
+        wgrad_acc(d1, w3_t.view(mid, hid), GbT.view(mid, d), dwo, None)
+        wgrad_acc(d2, Gb.view(d, mid), wo_f.view(d, hid), dw3, None)
+        part = part - Gb.view(d, mid).float()
+    db3 = None
+    if gs is not None and b3 is not None:
+        dwo.addr_(gs, b3)                                                        # u + W3 c + b3: the bias rides along with u
+        db3 = torch.mv(w_out.t(), gs)
+    return dwo, dw3, db3
+
+
+_deferred_ffn = {}    # id(W_out parameter) -> dict(G, gs, w_out, w3, refs of the parameters)
+
+
+def defer_ffn_grad(pw_out, pw3, pb3, w_out, w3, b3, need_b3: bool):
+    """The accumulators (G fp32 [d, mid], gs fp32 [d]) of one Conv-FFN for the in-place micro-batches of a step."""
+    import weakref
+    ent = _deferred_ffn.get(id(pw_out))
+    if ent is None or ent["pw_out"]() is not pw_out:
+        d, hid = w_out.shape
+        ent = dict(G=zeros_f32((d, w3.shape[1]), w_out.device), gs=zeros_f32((d,), w_out.device), w_out=w_out, w3=w3, b3=b3, need_b3=need_b3,
+                   pw_out=weakref.ref(pw_out), pw3=weakref.ref(pw3), pb3=weakref.ref(pb3) if pb3 is not None else None)
+        _deferred_ffn[id(pw_out)] = ent
+        in_place_params.add(id(pw3))
+        if pb3 is not None:
+            in_place_params.add(id(pb3))
+    return ent
+
+
+def take_deferred_ffn(pw_out):
+    """Pending accumulators of this Conv-FFN (None if there are none): the caller folds them into the gradients it returns."""
+    ent = _deferred_ffn.get(id(pw_out)) if pw_out is not None else None
+    if ent is None or ent["pw_out"]() is not pw_out:
+        return None
+    del _deferred_ffn[id(pw_out)]
+    return ent
+
+
+def flush_deferred_grads():
+    """Apply the chain rule of every pending composite gradient and ADD the results into the parameters' gradients."""
+    if not _deferred_ffn:
+        return
+    ents = list(_deferred_ffn.values())
+    _deferred_ffn.clear()
+    with torch.no_grad():
+        for ent in ents:
+            pw_out, pw3 = ent["pw_out"](), ent["pw3"]()
+            pb3 = ent["pb3"]() if ent["pb3"] is not None else None
+            if pw_out is None or pw3 is None:
+                continue
+            vo = grad_views(pw_out, ent["w_out"], None, False, force=True)
+            v3 = grad_views(pw3, ent["w3"], None, False, force=True)
+            dwo, dw3, db3 = ffn_chain_grads(ent["G"], ent["gs"] if ent["b3"] is not None else None, ent["w_out"], ent["w3"], ent["b3"],
+                                            out_w=vo[0] if vo is not None else None, out_w3=v3[0] if v3 is not None else None)
+            if not (pb3 is not None and ent["need_b3"]):
+                db3 = None
+            if vo is None:       # (no gradient buffer of the expected layout: fall back to torch's accumulation)
+                g_ = dwo.view_as(ent["w_out"])
+                pw_out.grad = g_.clone().view_as(pw_out) if pw_out.grad is None else pw_out.grad.add_(g_.reshape(pw_out.shape))
+            if v3 is None:
+                g_ = dw3.reshape(pw3.shape)
+                pw3.grad = g_.clone() if pw3.grad is None else pw3.grad.add_(g_)
+            if db3 is not None:
+                pb3.grad = db3 if pb3.grad is None else pb3.grad.add_(db3)
 
 
 def conv_dgrad(g: _Geo, w, gz, x_shape, residual=None, aux=None, aux_act: int = 0):

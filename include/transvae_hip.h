@@ -39,6 +39,10 @@ extern "C" {
  * same erf / exponential as the activation itself; tv_igemm_nt_actgrad(..., aux_act = TV_ACT_DERIV) then multiplies by
  * the saved tensor directly -- the backward epilogue carries no transcendental arithmetic. */
 #define TV_ACT_DERIV 3
+/* aux_act of tv_igemm_nt_actgrad only: the second tensor is ADDED, out = conv(x, w) + residual + aux -- two branch values
+ * joining the residual stream in one fp32 sum with ONE rounding (the collapsed Conv-FFN tail: t + W_out u + (W_out W3) c,
+ * R/transvae/modules/conv.py:85-104) */
+#define TV_ACT_ADD 4
 #define TV_ACT_SAVE_DERIV 16
 
 /* library ------------------------------------------------------------------ */
@@ -99,6 +103,7 @@ int tv_igemm_nt_rope(const tv_conv_desc* d, const void* x, const void* w, const 
  *     out = (conv(x, w) + residual) * act'(aux_pre_act)
  * i.e. the gradient w.r.t. the pre-activation tensor saved by the producing layer (aux_pre_act has the shape of
  * out).  Replaces autograd's GELU / SiLU backward (conv.py:56,86; upsample.py:35,96) without a separate pass.
+ * aux_act = TV_ACT_ADD:  out = conv(x, w) + residual + aux_pre_act  (a second residual; see TV_ACT_ADD).
  */
 int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const void* w, const void* residual,
                         const void* aux_pre_act, int aux_act, void* out, void* stream);

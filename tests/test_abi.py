@@ -26,9 +26,9 @@ def test_activation_ids_agree():
         return {k: int(v) for k, v in re.findall(r"#define\s+(TV_ACT_[A-Z_]+)\s+(\d+)", open(path).read())}
     pub = defines(os.path.join(ROOT, "include", "transvae_hip.h"))
     dev = defines(os.path.join(ROOT, "deepl-project_amd", "csrc", "common.h"))
-    assert pub == dev and len(pub) == 5, (pub, dev)
+    assert pub == dev and len(pub) == 6, (pub, dev)
     assert (pub["TV_ACT_NONE"], pub["TV_ACT_GELU"], pub["TV_ACT_SILU"]) == (_lib.ACT_NONE, _lib.ACT_GELU, _lib.ACT_SILU)
-    assert (pub["TV_ACT_DERIV"], pub["TV_ACT_SAVE_DERIV"]) == (_lib.ACT_DERIV, _lib.ACT_SAVE_DERIV)
+    assert (pub["TV_ACT_DERIV"], pub["TV_ACT_SAVE_DERIV"], pub["TV_ACT_ADD"]) == (_lib.ACT_DERIV, _lib.ACT_SAVE_DERIV, _lib.ACT_ADD)
     assert pub["TV_ACT_SAVE_DERIV"] & (pub["TV_ACT_GELU"] | pub["TV_ACT_SILU"] | pub["TV_ACT_DERIV"]) == 0
 
 

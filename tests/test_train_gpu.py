@@ -563,7 +563,8 @@ def _rccl_rank_main(port, q, grad_exchange):
             losses, norms, grads, pars = [], [], [], []
             for _ in range(2):          # DDP re-buckets after its first backward pass: two steps cover both bucket layouts
                 cursor[0] = 0
-                losses.append(float(train_step(mod, opt, x, 2, forward_loss, 1.0, 4, counters)))   # 2 micro-batches: no_sync + sync
+                # 4 micro-batches: autograd / in place under no_sync (x2: the Conv-FFN composite gradients are deferred) / sync
+                losses.append(float(train_step(mod, opt, x, 1, forward_loss, 1.0, 4, counters)))
                 torch.cuda.synchronize()
                 norms.append(float(counters["grad_norm"]))
                 grads.append({k: p.grad.detach().float().cpu().numpy().copy() for k, p in m.named_parameters()})
