@@ -46,6 +46,11 @@ struct IgemmArgs {
     unsigned out_bytes;   // extent of out (and of pre / res / aux: same shape) when below 2 GiB, else 0: the register epilogues
                           // address them through buffer descriptors with 32-bit offsets
     unsigned x_bytes, w_bytes;  // MODE 2: extents of the two buffers (< 2 GiB)
+    // two-source rows (tv_igemm_nt_cat2, eight-phase loop only): K-steps t >= k1_steps come from x2 (row pitch ldx2), i.e. the
+    // GEMM runs over the K-concatenation [x | x2] without the concatenated tensor existing
+    const bf16* x2;
+    unsigned x2_bytes;
+    int ldx2, k1_steps;
 };
 
 constexpr int LDS_MAX = 160 * 1024;

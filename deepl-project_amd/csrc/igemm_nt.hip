@@ -527,7 +527,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
         constexpr int QB0 = (WGN * 4) / 8;         // pieces per wave of region B_0 (2 or 1)
         const int grp = wave >> 2;
         // piece ownership by region: the r-th piece of a region (in row order) belongs to wave r % 8
-        int aq_voff[2][2], aq_lds[2][2], bq_voff[2][2], bq_lds[2][2];
+        int aq_voff[2][2], aq_voff2[2][2], aq_lds[2][2], bq_voff[2][2], bq_lds[2][2];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -536,6 +536,7 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
                 const int j = (r / PH) * (2 * PH) + a * PH + (r % PH);
                 const int row = j * RPI + srow, m = m0 + row;
                 aq_voff[a][q] = (m < p.M) ? (m * p.ldx + (sslot ^ swz_of<BK>(row & 15)) * 8) * 2 : OOB_OFFSET;   // single tap: pixel = m
+                aq_voff2[a][q] = (m < p.M) ? (m * p.ldx2 + (sslot ^ swz_of<BK>(row & 15)) * 8) * 2 : OOB_OFFSET; // rows of the second source
                 aq_lds[a][q] = j * 1024;
             }
 #pragma unroll
@@ -552,8 +553,13 @@ __global__ __launch_bounds__(WGM* WGN * 64, (igemm_min_waves<BM, BN, WGM * WGN, 
             }
         auto issue_A = [&](int t, int a) {
             char* sb = smem + (t & 1) * STAGE;
+            if (p.k1_steps > 0 && t >= p.k1_steps) {   // (wave-uniform) K-concatenated rows: this K-step lies in the second source
 #pragma unroll
-            for (int q = 0; q < 2; ++q) buffer_load_lds16(p.x, p.x_bytes, sb + aq_lds[a][q], aq_voff[a][q], t * (BK * 2));
+                for (int q = 0; q < 2; ++q) buffer_load_lds16(p.x2, p.x2_bytes, sb + aq_lds[a][q], aq_voff2[a][q], (t - p.k1_steps) * (BK * 2));
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) buffer_load_lds16(p.x, p.x_bytes, sb + aq_lds[a][q], aq_voff[a][q], t * (BK * 2));
+            }
         };
         auto issue_B = [&](int t, int b) {
             char* sb = smem + (t & 1) * STAGE;
@@ -966,6 +972,10 @@ int launch_one(const IgemmArgs& a_in, hipStream_t s) {
     if constexpr (BYTES > LDS_MAX) {
         return -1;
     } else {
+        if (a_in.x2) {   // two-source rows exist in the eight-phase loop only
+            constexpr bool P8OK = BM == 256 && ((BN == 256 && WGM == 2 && WGN == 4) || (BN == 192 && WGM == 4 && WGN == 2)) && BK == 64 && STAGES == 2 && MODE == 2;
+            if (!P8OK || !g_loop8 || g_persist != 0) return -2;
+        }
         const int tiles_m = (a_in.M + BM - 1) / BM;
         IgemmArgs a = a_in;
         a.tiles_m = tiles_m;
@@ -1179,8 +1189,13 @@ struct RopeSpec {
     const float* tab;
     int tokens, cols;
 };
+struct Cat2Spec {      // second source of K-concatenated rows: columns k1 .. c_in - 1 come from x2 (row pitch ldx2)
+    const void* x2;
+    int k1, ldx2;
+};
 static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
-                         void* pre_act, void* out, const void* aux, int aux_act, void* stream, RopeSpec rope = RopeSpec{nullptr, 0, 0});
+                         void* pre_act, void* out, const void* aux, int aux_act, void* stream, RopeSpec rope = RopeSpec{nullptr, 0, 0},
+                         Cat2Spec cat = Cat2Spec{nullptr, 0, 0});
 
 extern "C" int tv_igemm_nt_rope(const tv_conv_desc* d, const void* x, const void* w, const float* bias, void* out,
                                 const float* rope_tab, int tokens_per_image, int rope_cols, void* stream) {
@@ -1203,12 +1218,25 @@ extern "C" int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const v
     return igemm_nt_impl(d, x, w, nullptr, residual, nullptr, out, aux_pre_act, aux_act, stream);
 }
 
+extern "C" int tv_igemm_nt_cat2(const tv_conv_desc* d, const void* x, const void* x2, int k1, int ldx2, const void* w, const float* bias,
+                               const void* residual, const void* aux, int aux_act, void* out, void* stream) {
+    TV_CHECK_ARG(x2 && d && d->act == TV_ACT_NONE && (!aux || (aux_act >= 0 && aux_act <= TV_ACT_ADD && !bias)),
+                 "tv_igemm_nt_cat2: needs the second source, desc.act == NONE, and no bias together with aux");
+    return igemm_nt_impl(d, x, w, bias, residual, nullptr, out, aux, aux ? aux_act : TV_ACT_NONE, stream, RopeSpec{nullptr, 0, 0}, Cat2Spec{x2, k1, ldx2});
+}
+
 static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual,
-                         void* pre_act, void* out, const void* aux, int aux_act, void* stream, RopeSpec rope) {
+                         void* pre_act, void* out, const void* aux, int aux_act, void* stream, RopeSpec rope, Cat2Spec cat) {
     TV_CHECK_ARG(d && x && w && out, "tv_igemm_nt: null pointer");
+    if (cat.x2) {
+        TV_CHECK_ARG(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->up_shift == 0 && d->dil_mask == 0 && d->store_shuffle == 0 && !rope.tab,
+                     "tv_igemm_nt_cat2: single-tap layers only");
+        TV_CHECK_ARG(cat.k1 > 0 && cat.k1 % 64 == 0 && d->c_in > cat.k1 && (d->c_in - cat.k1) % 64 == 0 && d->ldx >= cat.k1 && d->ldx % 8 == 0 &&
+                     cat.ldx2 >= d->c_in - cat.k1 && cat.ldx2 % 8 == 0, "tv_igemm_nt_cat2: k1=%d c_in=%d ldx=%d ldx2=%d", cat.k1, d->c_in, d->ldx, cat.ldx2);
+    }
     TV_CHECK_ARG(d->c_in > 0 && d->c_in % 32 == 0, "tv_igemm_nt: c_in=%d must be a multiple of 32", d->c_in);
     TV_CHECK_ARG(d->c_out > 0 && d->c_out % 8 == 0, "tv_igemm_nt: c_out=%d must be a multiple of 8", d->c_out);
-    TV_CHECK_ARG(d->ldx >= d->c_in && d->ldx % 8 == 0, "tv_igemm_nt: ldx=%d (c_in=%d) must be >= c_in and a multiple of 8", d->ldx, d->c_in);
+    TV_CHECK_ARG(cat.x2 || (d->ldx >= d->c_in && d->ldx % 8 == 0), "tv_igemm_nt: ldx=%d (c_in=%d) must be >= c_in and a multiple of 8", d->ldx, d->c_in);
     TV_CHECK_ARG(d->ldo % 8 == 0, "tv_igemm_nt: ldo=%d must be a multiple of 8", d->ldo);
     TV_CHECK_ARG(d->batch > 0 && d->h_in > 0 && d->w_in > 0 && d->h_out > 0 && d->w_out > 0, "tv_igemm_nt: empty geometry");
     TV_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "tv_igemm_nt: bad taps");
@@ -1270,10 +1298,17 @@ static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, co
         fd(a.N >> 2, a.dv_cq_m, a.dv_cq_s);
     }
     {   // buffer-descriptor extents (0 = too large for 32-bit offsets -> global-address DMA)
-        const long long xb = ((long long)d->batch * d->h_in * d->w_in - 1) * d->ldx * 2 + (long long)d->c_in * 2;
+        const long long rows = (long long)d->batch * d->h_in * d->w_in;
+        const long long xb = (rows - 1) * d->ldx * 2 + (long long)(cat.x2 ? cat.k1 : d->c_in) * 2;
         const long long wb = (long long)a.N * a.K * 2;
         a.x_bytes = xb < (1ll << 31) ? (unsigned)xb : 0u;
         a.w_bytes = wb < (1ll << 31) ? (unsigned)wb : 0u;
+        a.x2 = (const bf16*)cat.x2;
+        a.ldx2 = cat.x2 ? cat.ldx2 : d->ldx;
+        a.k1_steps = cat.x2 ? cat.k1 / 64 : 0;
+        const long long x2b = cat.x2 ? (rows - 1) * cat.ldx2 * 2 + (long long)(d->c_in - cat.k1) * 2 : 0;
+        a.x2_bytes = (unsigned)x2b;
+        if (cat.x2 && (a.x_bytes == 0 || a.w_bytes == 0 || x2b >= (1ll << 31))) return TV_ERR_UNSUPPORTED;
     }
     {   // extent of the output tensor (shuffled stores: 4 M pixels of N / 4 channels; the polyphase grid is smaller still)
         const long long ob = d->store_shuffle ? ((4ll * M - 1) * d->ldo + (a.N >> 2)) * 2 : ((M - 1) * (long long)d->ldo + a.N) * 2;
@@ -1285,6 +1320,7 @@ static int igemm_nt_impl(const tv_conv_desc* d, const void* x, const void* w, co
     const bool bk64 = (d->c_in % 64 == 0) && g_cfg_bk != 32;
     int rc = (g_use_dma && g_use_halo && g_addr_mode != 1 && bk64) ? launch_halo(a, s) : -1;
     if (rc != 0) rc = bk64 ? launch_bk<64>(a, s) : launch_bk<32>(a, s);
+    if (rc != 0 && cat.x2) return TV_ERR_UNSUPPORTED;     // (the tile this shape takes has no two-source loop: the caller concatenates)
     if (rc != 0) {
         tv_set_error("tv_igemm_nt: no kernel for this configuration");
         return TV_ERR_ARG;

@@ -43,6 +43,7 @@ SIGNATURES = {
     "tv_igemm_nt": (_I, [_DP, _P, _P, _P, _P, _P, _P, _P]),
     "tv_igemm_nt_rope": (_I, [_DP, _P, _P, _P, _P, _P, _I, _I, _P]),
     "tv_igemm_nt_actgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P, _P]),
+    "tv_igemm_nt_cat2": (_I, [_DP, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "tv_wgrad_tn": (_I, [_DP, _P, _P, _P, _P, _P]),
     "tv_wgrad_tn_overwrites": (_I, [_DP]),
     "tv_wgrad_tn_acc": (_I, [_DP, _P, _P, _P, _P, _P]),

@@ -324,12 +324,15 @@ class ConvFFNBranchFn(torch.autograd.Function):
         mid = c1.shape[1]
         c2, pre_c2, geo2, w2c = conv_forward(c1.view(B, H, W, mid), w2, _c(b2), None, "c3s1", GELU, train and _WANT)
         w3c, w_out_c = w3.contiguous(), w_out.contiguous()
-        wc_f, wc_t, bc = ops.ffn_collapsed_operands(w_out_c, w3c, b3, b_out)
-        # the two branch values join the residual stream in ONE fp32 sum (TV_ACT_ADD): t itself is rounded once, as in
-        # the reference's order of operations (an intermediate t + ... in bf16 would round the stream a second time)
-        o1 = ops.gemm_rows(c2.view(T, mid), wc_f, d, bias=bc)                           # (W_out W3) c2 + W_out b3 + b_out
-        wo_f, _ = ops.pack_weight(w_out_c.view(d, 1, w_out_c.shape[1]), True, False, False)
-        out = ops.gemm_rows(u, wo_f.view(d, -1), d, residual=t, aux=o1, aux_act=L.ACT_ADD)      # t + W_out u + o1
+        wc_f, wc_t, bc, wcat_f = ops.ffn_collapsed_operands(w_out_c, w3c, b3, b_out)
+        # t + [u | c2] [W_out | Wc]^T + bc over the K-concatenation (one GEMM, nothing of [T, 4d + d] exists); shapes whose tile
+        # has no two-source loop: two GEMMs, the branch values joining the residual stream in ONE fp32 sum (TV_ACT_ADD) -- an
+        # intermediate t + ... in bf16 would round the stream a second time
+        out = ops.gemm_rows2(u, c2.view(T, mid), wcat_f, d, bias=bc, residual=t)
+        if out is None:
+            o1 = ops.gemm_rows(c2.view(T, mid), wc_f, d, bias=bc)                       # (W_out W3) c2 + W_out b3 + b_out
+            wo_f, _ = ops.pack_weight(w_out_c.view(d, 1, w_out_c.shape[1]), True, False, False)
+            out = ops.gemm_rows(u, wo_f.view(d, -1), d, residual=t, aux=o1, aux_act=L.ACT_ADD)   # t + W_out u + o1
         geo_out = ops._Geo("linear", u, w_out_c)
         ctx.geo = (geo_in, geo1, geo2, geo_out)
         _stash(ctx, (1, w_in), (2, b_in), (3, w1), (4, b1), (5, w2), (6, b2), (7, w3), (8, b3), (9, w_out), (10, b_out))
@@ -347,9 +350,6 @@ class ConvFFNBranchFn(torch.autograd.Function):
         hid = u.shape[1]
         g = g.contiguous()
         need = ctx.needs_input_grad
-        # d u = g W_out + gz_c1 W1 as ONE GEMM over K = d + mid (ops.ffn_du_operand): the operand rows are [g | gz_c1]
-        cat = torch.empty((T, d + mid), dtype=BF16, device=t.device)
-        cat[:, :d].copy_(g)
         # ---- the composite: G = g^T c2 (+ sum_t g), then the chain rule onto W_out, W3, b3 (deferred while in-place)
         gp = ctx.gparams
         p_out, p3, pb3 = gp.get(9), gp.get(7), gp.get(8)
@@ -357,9 +357,12 @@ class ConvFFNBranchFn(torch.autograd.Function):
         dw3 = db3 = dwo_chain = None
         deferred = False
         if need_chain:
-            views = ops.grad_views(p_out, w_out, gp.get(10), need[10]) if (need[9] and need[7] and p3 is not None) else None
+            can_defer = need[9] and need[7] and p3 is not None and p_out is not None
+            views = ops.grad_views(p_out, w_out, gp.get(10), need[10]) if can_defer else None
             dG = ops._rows_desc(T, mid, d)
-            if views is not None:       # in-place micro-batch: accumulate G and the column sums, chain rule at the end of the step
+            if views is not None or (can_defer and ops._defer_chain):
+                # in-place micro-batch (or any backward pass train_step marks): accumulate G and the column sums only; the
+                # chain rule runs once per optimizer step (ops.flush_deferred_grads)
                 ent = ops.defer_ffn_grad(p_out, p3, pb3, w_out, w3, b3, need[8])
                 ops.wgrad_acc(dG, c2.view(T, mid), g, ent["G"], ent["gs"])
                 deferred = True
@@ -377,9 +380,13 @@ class ConvFFNBranchFn(torch.autograd.Function):
         gz_c1 = conv_dgrad(geo2, w2, gz_c2, (B, H, W, mid), aux=pre_c1.view(B, H, W, mid), aux_act=_aux_act(GELU))
         dw2, db2 = _wg(ctx, 5, 6, geo2, w2, c1.view(B, H, W, mid), gz_c2)
         gz_c1 = gz_c1.view(T, mid)
-        cat[:, d:].copy_(gz_c1)
-        gz_u = ops.gemm_rows(cat, ops.ffn_du_operand(w_out, w1), hid, aux=pre_u, aux_act=_aux_act(GELU))   # (g W_out + gz_c1 W1) * gelu'(pre_u)
-        del cat
+        # d u = (g W_out + gz_c1 W1) * gelu'(pre_u) as ONE GEMM over the K-concatenation [g | gz_c1] (ops.ffn_du_operand)
+        w_du = ops.ffn_du_operand(w_out, w1)
+        gz_u = ops.gemm_rows2(g, gz_c1, w_du, hid, aux=pre_u, aux_act=_aux_act(GELU)) if _SAVE_DERIV else None
+        if gz_u is None:
+            cat = torch.cat([g, gz_c1], dim=1)
+            gz_u = ops.gemm_rows(cat, w_du, hid, aux=pre_u, aux_act=_aux_act(GELU))
+            del cat
         dw1, db1 = _wg(ctx, 3, 4, geo1, w1, u, gz_c1)
         dr = conv_dgrad(geo_in, w_in, gz_u, r.shape)
         dw_in, db_in = _wg(ctx, 1, 2, geo_in, w_in, r, gz_u)

@@ -308,6 +308,24 @@ acc_stats = {"in_place": 0, "autograd": 0}     # weight gradients added in place
 in_place_params = set()    # id(parameter) of every weight / bias a kernel has added into in place (transvae.parallel reads it)
 
 
+_defer_chain = False     # the Conv-FFN composite's chain rule waits for flush_deferred_grads() (set per micro-batch by train_step)
+
+
+@contextlib.contextmanager
+def defer_chain_grads(on: bool = True):
+    """Inside: ConvFFNBranchFn only accumulates the composite's gradient G; the chain rule onto W_out / W3 / b3 runs once, in
+    flush_deferred_grads() (end of the surrounding packed_weight_cache() block, or of this block when there is none).  For
+    backward passes after which nobody reads those gradients before the flush -- i.e. not the pass DDP reduces in."""
+    global _defer_chain
+    prev, _defer_chain = _defer_chain, bool(on)
+    try:
+        yield
+    finally:
+        _defer_chain = prev
+        if _pack_cache is None:
+            flush_deferred_grads()
+
+
 @contextlib.contextmanager
 def accumulate_grads_in_place(on: bool = True):
     global _accum_grads
@@ -567,8 +585,29 @@ def gemm_rows(x: torch.Tensor, wb: torch.Tensor, c_out: int, bias=None, residual
     return out
 
 
+def gemm_rows2(x1: torch.Tensor, x2: torch.Tensor, wb: torch.Tensor, c_out: int, bias=None, residual=None, aux=None, aux_act: int = 0):
+    """out[T, c_out] = [x1 | x2] wb[c_out, K1 + K2]^T (+ bias) (+ residual) (aux as in gemm_rows) WITHOUT forming the
+    concatenation (tv_igemm_nt_cat2: the eight-phase loop reads K-steps beyond K1 from x2).  None when the shape's tile has
+    no two-source loop (small problems): the caller takes its own fallback."""
+    T, K1 = x1.shape
+    K2 = x2.shape[1]
+    _require(x1.dtype == BF16 and x2.dtype == BF16 and x1.is_contiguous() and x2.is_contiguous() and x2.shape[0] == T and
+             tuple(wb.shape[-2:]) == (c_out, K1 + K2) or wb.numel() == c_out * (K1 + K2), "gemm_rows2: operand check failed")
+    if K1 % 64 or K2 % 64 or _batch_chunks(T, (x1, x2, residual, aux)) is not None:
+        return None
+    d = _rows_desc(T, K1 + K2, c_out)
+    d.ldx = K1
+    out = torch.empty((T, c_out), dtype=BF16, device=x1.device)
+    rc = L.load().tv_igemm_nt_cat2(C.byref(d), _p(x1), _p(x2), K1, K2, _p(wb), _p(bias), _p(residual), _p(aux), int(aux_act), _p(out), _stream())
+    if rc == 4:          # TV_ERR_UNSUPPORTED
+        return None
+    L.check(rc, "tv_igemm_nt_cat2")
+    return out
+
+
 def ffn_collapsed_operands(w_out: torch.Tensor, w3: torch.Tensor, b3, b_out):
-    """(Wc bf16 [d, mid], Wc^T bf16 [mid, d], bc fp32 [d]) for w_out [d, hid], w3 [hid, mid] fp32 parameter views."""
+    """(Wc bf16 [d, mid], Wc^T bf16 [mid, d], bc fp32 [d], [W_out | Wc] bf16 [d, hid + mid]) for w_out [d, hid], w3 [hid, mid]
+    fp32 parameter views."""
     d, hid = w_out.shape
     mid = w3.shape[1]
 
@@ -581,7 +620,7 @@ def ffn_collapsed_operands(w_out: torch.Tensor, w3: torch.Tensor, b3, b_out):
             bc = torch.mv(w_out, b3) if b_out is None else torch.addmv(b_out, w_out, b3)
         else:
             bc = b_out
-        return wc_f, wc_t, (bc.contiguous() if bc is not None else None)
+        return wc_f, wc_t, (bc.contiguous() if bc is not None else None), torch.cat([wo_f.view(d, hid), wc_f], dim=1)
     if _pack_cache is None:
         return build()
     bo, b3b = param_of(w_out), param_of(w3)
@@ -681,6 +720,9 @@ def flush_deferred_grads():
             pb3 = ent["pb3"]() if ent["pb3"] is not None else None
             if pw_out is None or pw3 is None:
                 continue
+            for pp in (pw_out, pw3):      # (a pass that deferred on the step's first micro-batch: no gradient of W3 exists yet)
+                if pp.grad is None:
+                    pp.grad = torch.zeros_like(pp, memory_format=torch.preserve_format)
             vo = grad_views(pw_out, ent["w_out"], None, False, force=True)
             v3 = grad_views(pw3, ent["w3"], None, False, force=True)
             dwo, dw3, db3 = ffn_chain_grads(ent["G"], ent["gs"] if ent["b3"] is not None else None, ent["w_out"], ent["w3"], ent["b3"],

@@ -197,6 +197,13 @@ def _swap_in_and_add(swapped):
         torch._foreach_add_(acc, new)
 
 
+def _defer_chain(x: torch.Tensor, on: bool):
+    if x.is_cuda and on:
+        from .hip import ops
+        return ops.defer_chain_grads(True)
+    return contextlib.nullcontext()
+
+
 def _packed_weight_cache(x: torch.Tensor):
     """The weights do not change between the micro-batches of a step: keep their bf16 repacks (HIP path only)."""
     if x.is_cuda:
@@ -289,7 +296,8 @@ def train_step(ddp_model: nn.Module, optimizer: torch.optim.Optimizer, x_local: 
             # the micro-batch that synchronises (also with ONE rank when the model is DDP-wrapped: wrap_ddp(force=True))
             in_place = i > 0 and (not hasattr(ddp_model, "no_sync") or not last)
             swapped = _swap_out_autograd_grads(params, x_local, in_place)
-            with sync_ctx, _accumulate_in_place(x_local, in_place):
+            # (the Conv-FFN composite gradients wait for the end of the step on every pass DDP does not reduce in)
+            with sync_ctx, _accumulate_in_place(x_local, in_place), _defer_chain(x_local, not hasattr(ddp_model, "no_sync") or not last):
                 loss = forward_loss(ddp_model, x_local[s:s + c]) * (c * world / global_batch)
                 loss.backward()
             _swap_in_and_add(swapped)

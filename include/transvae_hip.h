@@ -30,6 +30,7 @@ extern "C" {
 #define TV_ERR_ARG 1     /* bad shape / unsupported configuration */
 #define TV_ERR_LAUNCH 2  /* HIP reported a launch error */
 #define TV_ERR_INIT 3    /* no device / allocation of the zero page failed */
+#define TV_ERR_UNSUPPORTED 4 /* tv_igemm_nt_cat2 only: this shape's tile has no two-source loop -- concatenate and call tv_igemm_nt (no error text) */
 
 #define TV_ACT_NONE 0
 #define TV_ACT_GELU 1 /* exact (erf) GELU, R/transvae/modules/conv.py:56,86 */
@@ -107,6 +108,17 @@ int tv_igemm_nt_rope(const tv_conv_desc* d, const void* x, const void* w, const 
  */
 int tv_igemm_nt_actgrad(const tv_conv_desc* d, const void* x, const void* w, const void* residual,
                         const void* aux_pre_act, int aux_act, void* out, void* stream);
+
+/*
+ * The same GEMM over K-CONCATENATED rows that are never materialised (1x1 / Linear geometry only, desc.c_in = k1 + k2):
+ *     out = [x | x2] w^T (+ bias) (+ residual) (aux as in tv_igemm_nt_actgrad)
+ * x supplies columns 0 .. k1-1 (row pitch desc.ldx), x2 columns k1 .. c_in-1 (row pitch ldx2); k1 and c_in - k1 multiples of 64;
+ * w is [c_out][c_in] over the concatenated columns.  Two uses in the collapsed Conv-FFN tail (R/transvae/modules/conv.py:85-104):
+ * t + [u | c] [W_out | W_out W3]^T and the data gradient onto u, [g | gz_c] [W_out ; W1] * gelu'.  Only the eight-phase loop of
+ * the 256-row tiles has the second source: other shapes return TV_ERR_UNSUPPORTED (no error text) and the caller concatenates.
+ */
+int tv_igemm_nt_cat2(const tv_conv_desc* d, const void* x, const void* x2, int k1, int ldx2, const void* w, const float* bias,
+                     const void* residual, const void* aux, int aux_act, void* out, void* stream);
 
 /*
  * Weight gradient of the same layer (fp32):

@@ -988,3 +988,36 @@ def test_derived_3x3_operands_equal_the_slice_algebra(Cout, Cin):
                     kx = 1 if px == 0 else (2 if tx == 0 else 0)
                     wp[2 * py + px, :, ty, tx, :] = w[:, ky, kx, :].t()
     assert torch.equal(ops._s2_parity_weight(w, Cout, Cin), wp.to(BF).view(4 * Cin, 2, 2, Cout))
+
+
+# ---- K-concatenated rows from two tensors (tv_igemm_nt_cat2) against the GEMM over the materialised concatenation -----------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,K1,K2,N", [(4096, 384, 384, 1536), (2048 + 72, 1536, 384, 768), (1024, 64, 128, 768), (16384, 1536, 1536, 6144)])
+def test_two_source_rows_equal_the_concatenated_gemm(T, K1, K2, N):
+    """[x1 | x2] w^T with the eight-phase loop reading K-steps beyond K1 from the second tensor: the bits of the same GEMM on
+    torch.cat([x1, x2], 1) -- forward form (bias + residual), data-gradient form (saved-derivative multiply), plain; ragged
+    row tiles; K1 of one and of many K-steps; and None (the caller's fallback) where the tile has no two-source loop."""
+    from transvae.hip import _lib as L, ops
+    g = torch.Generator(device=dev()).manual_seed(T + K1 + N)
+    bf = torch.bfloat16
+    x1 = torch.randn(T, K1, device=dev(), generator=g).to(bf)
+    x2 = torch.randn(T, K2, device=dev(), generator=g).to(bf)
+    w = (torch.randn(N, K1 + K2, device=dev(), generator=g) * (K1 + K2) ** -0.5).to(bf)
+    b = torch.randn(N, device=dev(), generator=g) * 0.1
+    res = torch.randn(T, N, device=dev(), generator=g).to(bf)
+    der = torch.rand(T, N, device=dev(), generator=g).to(bf)
+    cat = torch.cat([x1, x2], 1)
+    lib = L.load()
+    try:
+        for bn in (256, 192):
+            lib.tv_set_igemm_config(256, bn, 0, 0)       # (the 256-row tiles whatever the heuristic says for this M: N is a multiple of 192 and, but once, of 256)
+            for kw in (dict(), dict(bias=b, residual=res), dict(aux=der, aux_act=L.ACT_DERIV), dict(residual=res, aux=der, aux_act=L.ACT_ADD)):
+                ref = ops.gemm_rows(cat, w, N, **kw)
+                for _ in range(2):
+                    got = ops.gemm_rows2(x1, x2, w, N, **kw)
+                    assert got is not None, "the 256-row tiles have the two-source loop"
+                    assert torch.equal(got, ref), (bn, sorted(kw), float((got.float() - ref.float()).abs().max()))
+    finally:
+        lib.tv_set_igemm_config(0, 0, 0, 0)
+    small = ops.gemm_rows2(x1[:64].contiguous(), x2[:64].contiguous(), w, N)      # (a 128-row tile: no two-source loop)
+    assert small is None or torch.equal(small, ops.gemm_rows(cat[:64].contiguous(), w, N))
