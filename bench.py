@@ -66,6 +66,23 @@ def init_scaled_(model, seed: int = 0):
                 p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=p.device))
 
 
+def _pmc_traffic(files, family: str, mb: int):
+    """HBM bytes per launch of one kernel family from the newest committed PMC summary that holds it (profiles/: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied by tools/probes/pmc_derive.py), scaled by the
+    image count.  NOT measured inside a bench run -- labelled so."""
+    for name in files:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            j = json.load(f).get(family)
+        if j and "hbm_bytes_per_launch" in j:
+            src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in their own runs, gfx950 corrections applied; "
+                   "not measured inside this run)" % name)
+            return round(j["hbm_bytes_per_launch"] * mb / j["images"]), src
+    return None, None
+
+
 def time_dominant_kernel(mb: int, res: int, dev):
     """HIP-event timing of tv_igemm_nt on the stage-0 ResBlock conv (192->192, 3x3, res x res)."""
     from transvae.hip import ops
@@ -88,13 +105,7 @@ def time_dominant_kernel(mb: int, res: int, dev):
     flop = 2.0 * mb * res * res * C * 9 * C
     # HBM bytes per launch: NOT measured in this run (PMC counters need their own rocprofv3 passes) -- read from the committed
     # summary of those passes over exactly this kernel and shape, scaled by the image count
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r03_dominant_kernel_pmc_all.json")
-    if os.path.exists(pmc) and res == 256:
-        with open(pmc) as f:
-            j = json.load(f)["conv3x3_halo"]
-        traffic = round(j["hbm_bytes_per_launch"] * mb / j["images"])
-        traffic_src = "profiles/" + os.path.basename(pmc) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --kernel-only`, gfx950 corrections applied; not measured inside this run)"
+    traffic, traffic_src = _pmc_traffic(("r04_dominant_kernel_pmc_all.json", "r03_dominant_kernel_pmc_all.json"), "conv3x3_halo", mb) if res == 256 else (None, None)
     return {"bound": "mfma", "kernel": "conv3x3_halo_kernel (the instantiation tv_igemm_nt selects) via tv_igemm_nt (conv3x3 192->192 @%dx%d, %d images)" % (res, res, mb),
             "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
@@ -105,7 +116,7 @@ def time_dominant_kernel(mb: int, res: int, dev):
 def time_linear_kernel(mb: int, dev):
     """HIP-event timing of the largest linear layer of the deepest stage (Conv-FFN proj_in, 1536 -> 6144 on 16 x 16 tokens per
     image) through tv_igemm_nt: igemm_nt_kernel<256,256,...> on its eight-phase ping-pong loop, the second largest GEMM
-    kernel family of the step by time (profiles/r03_rocprof_kernel_stats.csv)."""
+    kernel family of the step by time (profiles/r04_rocprof_kernel_stats.csv)."""
     from transvae.hip import ops
     from transvae.hip import _lib as L
     M, K, N = mb * 256, 1536, 6144
@@ -124,15 +135,16 @@ def time_linear_kernel(mb: int, dev):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     flop = 2.0 * M * K * N
+    traffic, traffic_src = _pmc_traffic(("r04_p8_gemm_pmc.json",), "igemm_nt", mb)
     return {"bound": "mfma", "kernel": "igemm_nt_kernel (the instantiation tv_igemm_nt selects) via tv_igemm_nt (linear 1536->6144, %d rows = %d images x 256 tokens)" % (M, mb),
             "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
-            "traffic": None, "traffic_source": None, "algorithmic_bytes_per_launch": (M * K + M * N + N * K) * 2}
+            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": (M * K + M * N + N * K) * 2}
 
 
 def time_wgrad_kernel(mb: int, res: int, dev):
     """HIP-event timing of the weight gradient (+ bias gradient) of the same stage-0 ResBlock convolution (tv_wgrad_tn ->
-    wgrad_kx3_kernel): the largest weight-gradient kernel of the step (profiles/r03_rocprof_kernel_stats.csv)."""
+    wgrad_kx3_kernel): the largest weight-gradient kernel of the step (profiles/r04_rocprof_kernel_stats.csv)."""
     from transvae.hip import ops
     C = 192
     x = torch.randn(mb, res, res, C, device=dev).to(torch.bfloat16)
@@ -154,14 +166,7 @@ def time_wgrad_kernel(mb: int, res: int, dev):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     flop = 2.0 * mb * res * res * C * 9 * C
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r03_dominant_kernel_pmc_all.json")
-    if os.path.exists(pmc) and res == 256:
-        with open(pmc) as f:
-            j = json.load(f).get("wgrad_kx3")
-        if j:
-            traffic = round(j["hbm_bytes_per_launch"] * mb / j["images"])
-            traffic_src = "profiles/r03_dominant_kernel_pmc_all.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --kernel-only`, gfx950 corrections applied; not measured inside this run)"
+    traffic, traffic_src = _pmc_traffic(("r04_dominant_kernel_pmc_all.json", "r03_dominant_kernel_pmc_all.json"), "wgrad_kx3", mb) if res == 256 else (None, None)
     return {"bound": "mfma", "kernel": "wgrad_kx3_kernel (the instantiation tv_wgrad_tn_acc selects) via tv_wgrad_tn_acc (weight + bias gradient of conv3x3 192->192 @%dx%d, %d images)" % (res, res, mb),
             "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(flop / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "flop_per_launch": flop, "ms_per_launch": round(ms, 4),
@@ -241,7 +246,10 @@ def main():
                          "torch: torch.optim.AdamW(fused=True) behind the same guard")
     ap.add_argument("--no-clamp", action="store_true", help="model without the P/ clamps (for the guard's A/B only)")
     ap.add_argument("--global-batch", type=int, default=256)
-    ap.add_argument("--micro-batch", type=int, default=64)
+    ap.add_argument("--micro-batch", type=int, default=0,
+                    help="images per micro-batch (at 256 x 256; other resolutions: the same pixels).  0 = 128 when the device holds "
+                         ">= 260 GiB (peak 245 GiB for Large: 159 images/s against 155 at 64 on one box, "
+                         "profiles/r04_kernel_experiments.txt item 8), else 64")
     ap.add_argument("--checkpointing", choices=["off", "resblocks", "all"], default="off",
                     help="activation recompute (R/transvae/models/encoder.py:97-99,117-118): resblocks = the fused-op recompute of the "
                          "CNN stages only (2 instead of 4 saved full-resolution tensors per ResBlock), all = every block like the reference")
@@ -268,8 +276,9 @@ def main():
                          "(they are then reported in config.tuning_env)")
     if args.kernel_only:
         torch.cuda.set_device(0)
-        r = time_dominant_kernel(args.micro_batch, args.res, torch.device("cuda", 0))
-        r["also"] = [time_wgrad_kernel(args.micro_batch, args.res, torch.device("cuda", 0)), time_linear_kernel(args.micro_batch, torch.device("cuda", 0))]
+        kmb = args.micro_batch if args.micro_batch > 0 else 64
+        r = time_dominant_kernel(kmb, args.res, torch.device("cuda", 0))
+        r["also"] = [time_wgrad_kernel(kmb, args.res, torch.device("cuda", 0)), time_linear_kernel(kmb, torch.device("cuda", 0))]
         print(json.dumps(r), flush=True)
         return
 
@@ -287,6 +296,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.micro_batch <= 0:
+        total_gib = torch.cuda.mem_get_info(dev)[1] / 2 ** 30
+        args.micro_batch = 128 if (total_gib >= 260 and args.variant in ("large", "base", "tiny")) else 64
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
     backend = args.dist_backend
     if backend == "auto":
@@ -422,10 +434,11 @@ def main():
             out["model_tflops_per_gpu"] = round(ips * gf / 1e3 / world, 1)
             out["mfma_roofline_frac"] = round(ips * gf / 1e3 / world / PEAK_BF16_TFLOPS, 4)
         log("timing the dominant kernel")
-        out["roofline"] = time_dominant_kernel(min(args.micro_batch, count), 256, dev)
-        # the dominant kernel BY TIME is the 3x3 convolution above (profiles/r03_rocprof_kernel_stats.csv: 15.5 % of the step);
+        kmb = min(args.micro_batch, count, 64)     # ONE launch: 64 images (a 128-image micro-batch's 3.2 GB tensors go out as two launches of 64)
+        out["roofline"] = time_dominant_kernel(kmb, 256, dev)
+        # the dominant kernel BY TIME is the 3x3 convolution above (profiles/r04_rocprof_kernel_stats.csv: 17 % of the step);
         # the largest weight-gradient kernel (9 %) is reported beside it
-        out["roofline"]["also"] = [time_wgrad_kernel(min(args.micro_batch, count), 256, dev), time_linear_kernel(min(args.micro_batch, count), dev)]
+        out["roofline"]["also"] = [time_wgrad_kernel(kmb, 256, dev), time_linear_kernel(kmb, dev)]
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle: 1 warm-up + 2 timed steps) ...")
             del model, ddp, opt

@@ -38,12 +38,30 @@ def _aux_act(act_id: int) -> int:
 # ------------------------------------------------------------------------------------------------
 # raw GroupNorm / row-norm / attention calls
 # ------------------------------------------------------------------------------------------------
+# Ablation hooks for UPPER BOUNDS on two fusions that are not built (VERDICT r03 row g; results are wrong by construction, only the
+# step time is read; bench.py refuses TV_* variables unless --allow-tuning-env and prints them into config.tuning_env):
+#   TV_ABL_SKIP_GN_STATS=1    no tv_gn_stats pass: statistics from a cached constant (mean = the pivot pixel, variance 1) -- what
+#                             GroupNorm statistics in the producing convolution's epilogue could save AT MOST (the epilogue work is free here)
+#   TV_ABL_SKIP_ROWNORM_FWD=1 no x-hat pass in front of the QKV / Conv-FFN projections -- what x-hat inside the GEMM could save at most
+_ABL_SKIP_GN_STATS = os.environ.get("TV_ABL_SKIP_GN_STATS") == "1"
+_ABL_SKIP_ROWNORM_FWD = os.environ.get("TV_ABL_SKIP_ROWNORM_FWD") == "1"
+_abl_stats = {}
+
+
 def gn_silu_fwd(x, gamma, beta, groups, eps):
     B, H, W, Cc = x.shape
     lib = L.load()
-    stats = torch.empty((B, Cc, 2), dtype=torch.float32, device=x.device)
-    part = torch.empty((lib.tv_gn_partial_count(B, H * W, Cc),), dtype=torch.float32, device=x.device)
-    L.check(lib.tv_gn_stats(_p(x), _p(stats), _p(part), B, H * W, Cc, _stream()), "tv_gn_stats")
+    if _ABL_SKIP_GN_STATS:
+        key = (B, H * W, Cc, x.device)
+        stats = _abl_stats.get(key)
+        if stats is None:
+            stats = torch.zeros((B, Cc, 2), dtype=torch.float32, device=x.device)
+            stats[..., 1] = float(H * W)
+            _abl_stats[key] = stats
+    else:
+        stats = torch.empty((B, Cc, 2), dtype=torch.float32, device=x.device)
+        part = torch.empty((lib.tv_gn_partial_count(B, H * W, Cc),), dtype=torch.float32, device=x.device)
+        L.check(lib.tv_gn_stats(_p(x), _p(stats), _p(part), B, H * W, Cc, _stream()), "tv_gn_stats")
     mr = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)
     L.check(lib.tv_gn_silu_fwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(mr), _p(y), B, H * W, Cc, groups, eps, _stream()),
@@ -77,6 +95,8 @@ def gn_silu_bwd(x, dy, dres, mr, gamma, beta, groups):
 
 def rownorm_fwd(x, w, mode, eps_rms, eps_ln):
     T, Cc = x.shape
+    if _ABL_SKIP_ROWNORM_FWD:
+        return x
     y = torch.empty_like(x)
     L.check(L.load().tv_rownorm_fwd(_p(x), _p(w), _p(y), T, Cc, mode, eps_rms, eps_ln, _stream()), "tv_rownorm_fwd")
     return y

@@ -4,7 +4,7 @@
 #   GEMM sweep, attention shapes.  Raw rocprofv3 output stays under gpurun_out/ (scratch); the summaries land in
 #   gpurun_out/profiles_<round>/ -- copy them into profiles/ (tracked).
 set -e
-R=${1:-r03}
+R=${1:-r04}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/profiles_$R; mkdir -p $OUT
@@ -43,5 +43,18 @@ python3 tools/probes/pmc_summary.py $OUT/${R}_gemm_kernels_pmc_raw.json \
     write=$(find $P/pmc_gemm_w -name "*counter_collection.csv" | head -1)
 python3 tools/probes/pmc_derive.py $OUT/${R}_gemm_kernels_pmc_raw.json $OUT/${R}_gemm_kernels_pmc.json images=64 note="tools/gemm_sweep.py --mb 64 --only res192@256: forward + data gradient (conv3x3_halo), weight gradient without bias (wgrad_kx3)"
 python3 tools/probes/pmc_derive.py $OUT/${R}_attention_pmc_raw.json $OUT/${R}_attention_pmc.json images=64
+echo "[7] eight-phase linear kernel alone: 1536 -> 6144 on 16384 rows (the kernel of bench.py's third roofline entry), 40 launches"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/pmc_p8_f -o f -- python3 tools/probes/p8_pmc_run.py 16384 1536 6144 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/pmc_p8_w -o w -- python3 tools/probes/p8_pmc_run.py 16384 1536 6144 > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $P/pmc_p8_s -o s -- python3 tools/probes/p8_pmc_run.py 16384 1536 6144 > /dev/null 2>&1
+python3 tools/probes/pmc_summary.py $OUT/${R}_p8_gemm_pmc_raw.json \
+    fetch=$(find $P/pmc_p8_f -name "*counter_collection.csv" | head -1) \
+    write=$(find $P/pmc_p8_w -name "*counter_collection.csv" | head -1) \
+    sq=$(find $P/pmc_p8_s -name "*counter_collection.csv" | head -1)
+python3 tools/probes/pmc_derive.py $OUT/${R}_p8_gemm_pmc_raw.json $OUT/${R}_p8_gemm_pmc.json images=64 note="tools/probes/p8_pmc_run.py 16384 1536 6144: igemm_nt_kernel<256,256,...> on the eight-phase loop, linear 1536->6144 forward (bias), 16384 rows = 64 images x 256 tokens, super-tile block order 4 x 8, 40 launches"
+echo "[8] block traces and launch census"
+python3 tools/probes/block_trace.py 384 64 64 > $OUT/${R}_block_trace_stage2.txt 2>&1
+python3 tools/probes/block_trace.py 1536 16 64 > $OUT/${R}_block_trace_stage4.txt 2>&1
+python3 tools/probes/launch_census.py large > $OUT/${R}_launch_census.txt 2>&1
 rm -rf $P
 ls -la $OUT
