@@ -974,7 +974,7 @@ int launch_one(const IgemmArgs& a_in, hipStream_t s) {
     } else {
         if (a_in.x2) {   // two-source rows exist in the eight-phase loop only
             constexpr bool P8OK = BM == 256 && ((BN == 256 && WGM == 2 && WGN == 4) || (BN == 192 && WGM == 4 && WGN == 2)) && BK == 64 && STAGES == 2 && MODE == 2;
-            if (!P8OK || !g_loop8 || g_persist != 0) return -2;
+            if (!P8OK || !g_loop8) return -2;
         }
         const int tiles_m = (a_in.M + BM - 1) / BM;
         IgemmArgs a = a_in;
@@ -1017,7 +1017,7 @@ int launch_one(const IgemmArgs& a_in, hipStream_t s) {
             const int em = epilogue_mode(a);
             const bool reg_epi = em != 0 || a.form == EF_PLAIN || a.form == EF_GELU_D || a.form == EF_RES_DERIV || a.form == EF_ROPE;
             const bool single_tap = a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.up_shift == 0 && a.dil_mask == 0;
-            if (g_persist != 0 && reg_epi && single_tap && a.M % BM == 0 && a.N % BN == 0) {
+            if (g_persist != 0 && !a.x2 && reg_epi && single_tap && a.M % BM == 0 && a.N % BN == 0) {   // (two-source rows: eight-phase loop only)
                 const int nlist = ((tiles_m + 7) / 8) * a.tiles_n;      // longest per-XCD list
                 int W = (nlist + 31) / 32;                              // 32 block slots per XCD
                 if (g_persist > 1) W = g_persist < nlist ? g_persist : nlist;   // (tuning hook: forced walk length)

@@ -15,12 +15,34 @@ namespace {
 constexpr int GN_THREADS = 256;
 constexpr int GN_PIX_PER_BLOCK = 512;
 
+// Streaming accesses of the GroupNorm passes.  A ResBlock tensor is 0.4-1.6 GB at micro-batch 64, read or written once per pass
+// and far beyond the 256 MiB Infinity Cache: with the NON-TEMPORAL policy on loads and stores the four kernels move 5.7-5.8
+// TB/s instead of 5.1-5.4 (tools/probes/gn_bench.py, two interleaved repetitions: 6.167 -> 5.765 ms over the passes of one
+// 256 x 256 and one 128 x 128 GroupNorm forward + backward; loads alone 6.04; a deeper unroll nothing).  NT is a kernel template
+// parameter chosen per launch by the tensor's size (gn_nt): small tensors keep the default policy -- their consumer finds
+// them in the cache.  TV_GN_NT_MIB (compile time): threshold in MiB, -1 = never.
+#ifndef TV_GN_NT_MIB
+#define TV_GN_NT_MIB 128
+#endif
+template <bool NT>
+__device__ __forceinline__ bf16x8 gn_ld(const bf16* p) {
+    if constexpr (NT) return __builtin_nontemporal_load((const bf16x8*)p);
+    else return *(const bf16x8*)p;
+}
+template <bool NT>
+__device__ __forceinline__ void gn_st(bf16* p, const bf16x8& v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, (bf16x8*)p);
+    else *(bf16x8*)p = v;
+}
+static bool gn_nt(int batch, int hw, int C) { return TV_GN_NT_MIB >= 0 && (long long)batch * hw * C * 2 >= ((long long)TV_GN_NT_MIB << 20); }
+
 // ---- GroupNorm: per-(b,c) sum / sum of squares ABOUT A PIVOT --------------------------------------
 // The one-pass form var = E[x^2] - mean^2 cancels when |mean| >> std (a residual stream whose mean has drifted; up to
 // ~400 K elements per group in fp32).  All sums are therefore taken about the pivot piv[b][c] = x[b, pixel 0, c] (the
 // same for every block of the image, so the partials still add in a fixed order), and gn_prepare merges the channels
 // of a group with Chan's parallel (mean, M2) update -- the result matches a two-pass / Welford computation like
 // ATen's group_norm to fp32 rounding.
+template <bool NT>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16* __restrict__ x, float* __restrict__ part,
                                                               int hw, int C) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -38,7 +60,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16* __rest
         const bf16* base = x + ((size_t)b * hw) * C + chunk * 8;
         const bf16x8 pv = *(const bf16x8*)base;   // pivot: pixel 0 of this image
         for (int p = p0 + prow; p < p1; p += rows) {
-            const bf16x8 v = *(const bf16x8*)(base + (size_t)p * C);
+            const bf16x8 v = gn_ld<NT>(base + (size_t)p * C);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float f = (float)v[e] - (float)pv[e];
@@ -110,7 +132,7 @@ __device__ __forceinline__ void gn_prepare(const float* stats_b, const bf16* x_b
 
 // FROM_MR: the statistics are READ from mr (the mean / rstd a forward call wrote) instead of being derived from the channel
 // sums -- the recompute of silu(gn(x)) in the backward pass of a checkpointed ResBlock: same scale / shift bits, same output.
-template <bool FROM_MR>
+template <bool FROM_MR, bool NT>
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ stats,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float* __restrict__ mr, bf16* __restrict__ y, int hw, int C, int G,
@@ -155,15 +177,16 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_fwd_kernel(const bf16* __r
 #pragma unroll 2
     for (int px = p0 + prow; px < p1; px += rows) {
         const size_t off = (img + px) * C + chunk * 8;
-        const bf16x8 v = *(const bf16x8*)(x + off);
+        const bf16x8 v = gn_ld<NT>(x + off);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)tv_silu(fmaf((float)v[e], sc[e], sh[e]));
-        *(bf16x8*)(y + off) = o;
+        gn_st<NT>(y + off, o);
     }
 }
 
 // backward pass 1: red[b][c] += (sum dh, sum dh*xhat),  dh = dy * silu'(h)
+template <bool NT>
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reduce_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                                         const float* __restrict__ mr, const float* __restrict__ gamma,
                                                                         const float* __restrict__ beta, float* __restrict__ part, int hw,
@@ -189,8 +212,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reduce_kernel(const bf
         }
         const size_t base = ((size_t)b * hw) * C + chunk * 8;
         for (int p = p0 + prow; p < p1; p += rows) {
-            const bf16x8 xv = *(const bf16x8*)(x + base + (size_t)p * C);
-            const bf16x8 gv = *(const bf16x8*)(dy + base + (size_t)p * C);
+            const bf16x8 xv = gn_ld<NT>(x + base + (size_t)p * C);
+            const bf16x8 gv = gn_ld<NT>(dy + base + (size_t)p * C);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float xh = ((float)xv[e] - mean[e]) * rstd[e];
@@ -217,6 +240,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reduce_kernel(const bf
 }
 
 // backward pass 2: dx = rstd*(dh*gamma - (S1_g + xhat*S2_g)/n) (+ dres)
+template <bool NT>
 __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                                        const bf16* __restrict__ dres, const float* __restrict__ mr,
                                                                        const float* __restrict__ red, const float* __restrict__ gamma,
@@ -284,10 +308,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_apply_kernel(const bf1
 #pragma unroll 2
     for (int px = p0 + prow; px < p1; px += rows) {
         const size_t off = (img + px) * C + chunk * 8;
-        const bf16x8 xv = *(const bf16x8*)(x + off);
-        const bf16x8 gv = *(const bf16x8*)(dy + off);
+        const bf16x8 xv = gn_ld<NT>(x + off);
+        const bf16x8 gv = gn_ld<NT>(dy + off);
         bf16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (dres) rv = *(const bf16x8*)(dres + off);
+        if (dres) rv = gn_ld<NT>(dres + off);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -297,7 +321,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_apply_kernel(const bf1
             const float d = fmaf(dh, cA[e], fmaf(-xf, cC[e], cD[e]));
             o[e] = (bf16)(d + (float)rv[e]);
         }
-        *(bf16x8*)(dx + off) = o;
+        gn_st<NT>(dx + off, o);
     }
 }
 
@@ -533,7 +557,8 @@ extern "C" int tv_gn_stats(const void* x, float* stats, float* partials, int bat
     if (gn_check("tv_gn_stats", batch, hw, C, 1)) return TV_ERR_ARG;
     TV_CHECK_ARG(x && stats && partials, "tv_gn_stats: null pointer");
     dim3 grid(tv_cdiv(hw, GN_PIX_PER_BLOCK), batch);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), gn_lds_bytes(C), (hipStream_t)stream, (const bf16*)x, partials, hw, C);
+    if (gn_nt(batch, hw, C)) hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(GN_THREADS), gn_lds_bytes(C), (hipStream_t)stream, (const bf16*)x, partials, hw, C);
+    else hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(GN_THREADS), gn_lds_bytes(C), (hipStream_t)stream, (const bf16*)x, partials, hw, C);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(tv_cdiv(2 * C, 256), batch), dim3(256), 0, (hipStream_t)stream, (const float*)partials, stats,
                        (int)grid.x, 2 * C);
     TV_CHECK_LAUNCH("tv_gn_stats");
@@ -545,8 +570,12 @@ extern "C" int tv_gn_silu_fwd(const void* x, const float* stats, const float* ga
     if (gn_check("tv_gn_silu_fwd", batch, hw, C, G)) return TV_ERR_ARG;
     TV_CHECK_ARG(x && stats && gamma && beta && mr && y, "tv_gn_silu_fwd: null pointer");
     dim3 grid(tv_cdiv(hw, GN_PIX_PER_BLOCK), batch);
-    hipLaunchKernelGGL(gn_silu_fwd_kernel<false>, grid, dim3(GN_THREADS), (2 * C + 2 * G) * sizeof(float), (hipStream_t)stream, (const bf16*)x,
-                       stats, gamma, beta, mr, (bf16*)y, hw, C, G, eps);
+    if (gn_nt(batch, hw, C))
+        hipLaunchKernelGGL((gn_silu_fwd_kernel<false, true>), grid, dim3(GN_THREADS), (2 * C + 2 * G) * sizeof(float), (hipStream_t)stream,
+                           (const bf16*)x, stats, gamma, beta, mr, (bf16*)y, hw, C, G, eps);
+    else
+        hipLaunchKernelGGL((gn_silu_fwd_kernel<false, false>), grid, dim3(GN_THREADS), (2 * C + 2 * G) * sizeof(float), (hipStream_t)stream,
+                           (const bf16*)x, stats, gamma, beta, mr, (bf16*)y, hw, C, G, eps);
     TV_CHECK_LAUNCH("tv_gn_silu_fwd");
     return TV_OK;
 }
@@ -556,8 +585,12 @@ extern "C" int tv_gn_silu_apply(const void* x, const float* mr, const float* gam
     if (gn_check("tv_gn_silu_apply", batch, hw, C, G)) return TV_ERR_ARG;
     TV_CHECK_ARG(x && mr && gamma && beta && y, "tv_gn_silu_apply: null pointer");
     dim3 grid(tv_cdiv(hw, GN_PIX_PER_BLOCK), batch);
-    hipLaunchKernelGGL(gn_silu_fwd_kernel<true>, grid, dim3(GN_THREADS), (2 * C + 2 * G) * sizeof(float), (hipStream_t)stream, (const bf16*)x,
-                       nullptr, gamma, beta, const_cast<float*>(mr), (bf16*)y, hw, C, G, 0.f);
+    if (gn_nt(batch, hw, C))
+        hipLaunchKernelGGL((gn_silu_fwd_kernel<true, true>), grid, dim3(GN_THREADS), (2 * C + 2 * G) * sizeof(float), (hipStream_t)stream,
+                           (const bf16*)x, nullptr, gamma, beta, const_cast<float*>(mr), (bf16*)y, hw, C, G, 0.f);
+    else
+        hipLaunchKernelGGL((gn_silu_fwd_kernel<true, false>), grid, dim3(GN_THREADS), (2 * C + 2 * G) * sizeof(float), (hipStream_t)stream,
+                           (const bf16*)x, nullptr, gamma, beta, const_cast<float*>(mr), (bf16*)y, hw, C, G, 0.f);
     TV_CHECK_LAUNCH("tv_gn_silu_apply");
     return TV_OK;
 }
@@ -567,8 +600,12 @@ extern "C" int tv_gn_silu_bwd_reduce(const void* x, const void* dy, const float*
     if (gn_check("tv_gn_silu_bwd_reduce", batch, hw, C, G)) return TV_ERR_ARG;
     TV_CHECK_ARG(x && dy && mr && gamma && beta && red && partials, "tv_gn_silu_bwd_reduce: null pointer");
     dim3 grid(tv_cdiv(hw, GN_PIX_PER_BLOCK), batch);
-    hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel, grid, dim3(GN_THREADS), gn_lds_bytes(C), (hipStream_t)stream, (const bf16*)x,
-                       (const bf16*)dy, mr, gamma, beta, partials, hw, C, G);
+    if (gn_nt(batch, hw, C))
+        hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel<true>, grid, dim3(GN_THREADS), gn_lds_bytes(C), (hipStream_t)stream, (const bf16*)x,
+                           (const bf16*)dy, mr, gamma, beta, partials, hw, C, G);
+    else
+        hipLaunchKernelGGL(gn_silu_bwd_reduce_kernel<false>, grid, dim3(GN_THREADS), gn_lds_bytes(C), (hipStream_t)stream, (const bf16*)x,
+                           (const bf16*)dy, mr, gamma, beta, partials, hw, C, G);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(tv_cdiv(2 * C, 256), batch), dim3(256), 0, (hipStream_t)stream, (const float*)partials, red,
                        (int)grid.x, 2 * C);
     TV_CHECK_LAUNCH("tv_gn_silu_bwd_reduce");
@@ -581,8 +618,12 @@ extern "C" int tv_gn_silu_bwd_apply(const void* x, const void* dy, const void* d
     if (gn_check("tv_gn_silu_bwd_apply", batch, hw, C, G)) return TV_ERR_ARG;
     TV_CHECK_ARG(x && dy && mr && red && gamma && beta && dx && dgamma && dbeta, "tv_gn_silu_bwd_apply: null pointer");
     dim3 grid(tv_cdiv(hw, GN_PIX_PER_BLOCK), batch);
-    hipLaunchKernelGGL(gn_silu_bwd_apply_kernel, grid, dim3(GN_THREADS), (6 * C + 2 * G) * sizeof(float), (hipStream_t)stream,
-                       (const bf16*)x, (const bf16*)dy, (const bf16*)dres, mr, red, gamma, beta, (bf16*)dx, dgamma, dbeta, hw, C, G);
+    if (gn_nt(batch, hw, C))
+        hipLaunchKernelGGL(gn_silu_bwd_apply_kernel<true>, grid, dim3(GN_THREADS), (6 * C + 2 * G) * sizeof(float), (hipStream_t)stream,
+                           (const bf16*)x, (const bf16*)dy, (const bf16*)dres, mr, red, gamma, beta, (bf16*)dx, dgamma, dbeta, hw, C, G);
+    else
+        hipLaunchKernelGGL(gn_silu_bwd_apply_kernel<false>, grid, dim3(GN_THREADS), (6 * C + 2 * G) * sizeof(float), (hipStream_t)stream,
+                           (const bf16*)x, (const bf16*)dy, (const bf16*)dres, mr, red, gamma, beta, (bf16*)dx, dgamma, dbeta, hw, C, G);
     TV_CHECK_LAUNCH("tv_gn_silu_bwd_apply");
     return TV_OK;
 }

@@ -42,7 +42,8 @@ def _aux_act(act_id: int) -> int:
 # step time is read; bench.py refuses TV_* variables unless --allow-tuning-env and prints them into config.tuning_env):
 #   TV_ABL_SKIP_GN_STATS=1    no tv_gn_stats pass: statistics from a cached constant (mean = the pivot pixel, variance 1) -- what
 #                             GroupNorm statistics in the producing convolution's epilogue could save AT MOST (the epilogue work is free here)
-#   TV_ABL_SKIP_ROWNORM_FWD=1 no x-hat pass in front of the QKV / Conv-FFN projections -- what x-hat inside the GEMM could save at most
+#   TV_ABL_SKIP_ROWNORM_FWD=1 no x-hat pass in front of the QKV / Conv-FFN projections (the first x-hat of a shape is reused: finite, wrong)
+#                             -- what x-hat inside the GEMM could save at most
 _ABL_SKIP_GN_STATS = os.environ.get("TV_ABL_SKIP_GN_STATS") == "1"
 _ABL_SKIP_ROWNORM_FWD = os.environ.get("TV_ABL_SKIP_ROWNORM_FWD") == "1"
 _abl_stats = {}
@@ -95,10 +96,14 @@ def gn_silu_bwd(x, dy, dres, mr, gamma, beta, groups):
 
 def rownorm_fwd(x, w, mode, eps_rms, eps_ln):
     T, Cc = x.shape
-    if _ABL_SKIP_ROWNORM_FWD:
-        return x
+    if _ABL_SKIP_ROWNORM_FWD:       # (timing ablation: the first x-hat of this shape stands in for every later one -- finite, wrong)
+        hit = _abl_stats.get(("rownorm", T, Cc, mode, x.device))
+        if hit is not None:
+            return hit
     y = torch.empty_like(x)
     L.check(L.load().tv_rownorm_fwd(_p(x), _p(w), _p(y), T, Cc, mode, eps_rms, eps_ln, _stream()), "tv_rownorm_fwd")
+    if _ABL_SKIP_ROWNORM_FWD:
+        _abl_stats[("rownorm", T, Cc, mode, x.device)] = y
     return y
 
 

@@ -831,7 +831,7 @@ def test_persistent_column_loop_is_bit_identical_to_one_tile_per_block(M, K, N):
             lib.tv_set_igemm_persist(walk)
             got[walk] = cases()
     finally:
-        lib.tv_set_igemm_persist(1)
+        lib.tv_set_igemm_persist(0)      # (the library's default: the walk is off)
         lib.tv_set_igemm_config(0, 0, 0, 0)
     for walk, res_w in got.items():
         for k in ref:

@@ -458,6 +458,12 @@ def test_large_f16d32_256_full_size_properties_and_oracle():
     assert errs[1] < max(1e-2, r16["mu"]) and errs[2] < max(1e-2, r16["logvar"]), errs
     assert e_dec < max(1e-2, r16["recon"]), e_dec
     assert e_path < max(1e-2, r16["recon"]), (e_path, e_prop)
+    # end-to-end sanity: the full reconstruction error is the sum of the two parts of the exact split, so it can
+    # never exceed e_path + e_prop (triangle inequality, rounding of the norms aside); an encoder drift that stays inside the
+    # mu / logvar tolerance but blows up through the sampling would show here as an e_prop far above what a 1.1e-2 logvar
+    # error makes of it at these weights (measured 1.1-1.8e-2 at 256 px, 2.6e-2 at 512 px): an absolute ceiling of 6e-2
+    assert errs[0] <= 1.001 * (e_path + e_prop) + 1e-6, (errs[0], e_path, e_prop)
+    assert e_prop < 6e-2, e_prop
 
 
 def test_large_f16d32_256_gradients_add_over_images():
@@ -655,6 +661,12 @@ def test_large_512_one_image_forward_against_oracle():
     assert errs[1] < max(1e-2, r16["mu"]) and errs[2] < max(1e-2, r16["logvar"]), errs
     assert e_dec < max(1e-2, r16["recon"]), e_dec
     assert e_path < max(1e-2, r16["recon"]), (e_path, e_prop)
+    # end-to-end sanity: the full reconstruction error is the sum of the two parts of the exact split, so it can
+    # never exceed e_path + e_prop (triangle inequality, rounding of the norms aside); an encoder drift that stays inside the
+    # mu / logvar tolerance but blows up through the sampling would show here as an e_prop far above what a 1.1e-2 logvar
+    # error makes of it at these weights (measured 1.1-1.8e-2 at 256 px, 2.6e-2 at 512 px): an absolute ceiling of 6e-2
+    assert errs[0] <= 1.001 * (e_path + e_prop) + 1e-6, (errs[0], e_path, e_prop)
+    assert e_prop < 6e-2, e_prop
 
 
 def _sampled_err(t, g, name):
