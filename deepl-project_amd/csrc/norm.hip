@@ -59,6 +59,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const bf16* __rest
         for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
         const bf16* base = x + ((size_t)b * hw) * C + chunk * 8;
         const bf16x8 pv = *(const bf16x8*)base;   // pivot: pixel 0 of this image
+#pragma unroll 2
         for (int p = p0 + prow; p < p1; p += rows) {
             const bf16x8 v = gn_ld<NT>(base + (size_t)p * C);
 #pragma unroll
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_silu_bwd_reduce_kernel(const bf
             s[e] = q[e] = 0.f;
         }
         const size_t base = ((size_t)b * hw) * C + chunk * 8;
+#pragma unroll 2
         for (int p = p0 + prow; p < p1; p += rows) {
             const bf16x8 xv = gn_ld<NT>(x + base + (size_t)p * C);
             const bf16x8 gv = gn_ld<NT>(dy + base + (size_t)p * C);

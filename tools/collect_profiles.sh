@@ -15,7 +15,7 @@ cp $(find $P/bench -name "*kernel_stats.csv" | head -1) $OUT/${R}_rocprof_kernel
 echo "[2] dominant kernel alone"
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/konly -o konly -- python3 bench.py --kernel-only --micro-batch 64 > $P/konly.log 2>&1
 cp $(find $P/konly -name "*kernel_stats.csv" | head -1) $OUT/${R}_rocprof_kernel_only_stats.csv
-tail -1 $P/konly.log > $OUT/${R}_kernel_only_hip_events.json
+grep '^{' $P/konly.log | tail -1 > $OUT/${R}_kernel_only_hip_events.json
 echo "[3] PMC passes (each in its own run)"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/pmc_fetch -o f -- python3 bench.py --kernel-only --micro-batch 64 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/pmc_write -o w -- python3 bench.py --kernel-only --micro-batch 64 > /dev/null 2>&1

@@ -46,7 +46,9 @@ def layer_list(variant, res, mb):
                 add(f"ffn_in{d}@{H}", "linear", T, d, 4 * d, depths[i])
                 add(f"ffn_c0{d}@{H}", "linear", T, 4 * d, d, depths[i])
                 add(f"ffn_c3x3{d}@{H}", "c3s1", H, d, d, depths[i])
-                add(f"ffn_c4{d}@{H}", "linear", T, d, 4 * d, depths[i])
+                # round 4: conv.4 (d -> 4d) runs collapsed into the composite Wc = W_out W3 (d -> d): its forward rides in
+                # proj_out's launch as a second K source, its data / weight gradients are d -> d launches
+                add(f"ffn_wc{d}@{H}", "linear", T, d, d, depths[i])
                 add(f"ffn_out{d}@{H}", "linear", T, 4 * d, d, depths[i])
         for i in range(n - 1):
             H = res >> i
