@@ -298,7 +298,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if args.micro_batch <= 0:
         total_gib = torch.cuda.mem_get_info(dev)[1] / 2 ** 30
-        args.micro_batch = 128 if (total_gib >= 260 and args.variant in ("large", "base", "tiny")) else 64
+        if args.variant in ("giant", "huge"):       # (giant: 4.6 GiB of activations per image beside 88 GiB of state)
+            args.micro_batch = 32
+        else:
+            args.micro_batch = 128 if total_gib >= 260 else 64
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
     backend = args.dist_backend
     if backend == "auto":

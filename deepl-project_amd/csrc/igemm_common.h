@@ -117,7 +117,7 @@ using namespace tvi;
 #define TV_GENERIC_DPHASE 1   // generic pipelined loop: DMA slots staggered by wave through a run-time phase (scalar branches in the MFMA stream)
 #endif
 #ifndef TV_PERSIST_DRAIN
-#define TV_PERSIST_DRAIN 0    // persistent column loop: 1 = open every tile with vmcnt(0) (drains the previous tile's stores too), for A/B
+#define TV_PERSIST_DRAIN 1    // persistent column loop (off by default, tv_set_igemm_persist): 1 = open every tile with vmcnt(0) -- drains the previous tile's stores too, no hand-counted wait; 0 = the counted vmcnt(NST) form, for A/B
 #endif
 #ifndef TV_NO_PINGPONG
 #define TV_NO_PINGPONG 1   // ping-pong main loop of the 8-wave tiles: measured, not (yet) a win -- see DESIGN.md
