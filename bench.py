@@ -262,6 +262,9 @@ def main():
                     help="auto: nccl (= RCCL) whenever the process was started by torch.distributed.run (RANK / WORLD_SIZE in the "
                          "environment), also with ONE rank -- DDP, its bucket views and the all-reduce then run exactly as at N > 1; "
                          "none with a plain `python bench.py`")
+    ap.add_argument("--mem-fraction", type=float, default=0.0,
+                    help="cap this process's share of the device memory (torch.cuda.set_per_process_memory_fraction): rehearses the "
+                         "fallback of the automatic micro-batch on a smaller device")
     ap.add_argument("--allow-tuning-env", action="store_true",
                     help="run although TV_* tuning variables are set (they are printed into config.tuning_env either way)")
     ap.add_argument("--kernel-only", action="store_true", help="only time the dominant kernel (for rocprofv3 --pmc passes)")
@@ -296,7 +299,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if args.micro_batch <= 0:
+    if args.mem_fraction > 0:
+        torch.cuda.set_per_process_memory_fraction(args.mem_fraction, dev)
+    auto_mb = args.micro_batch <= 0
+    if auto_mb:
         total_gib = torch.cuda.mem_get_info(dev)[1] / 2 ** 30
         if args.variant in ("giant", "huge"):       # (giant: 4.6 GiB of activations per image beside 88 GiB of state)
             args.micro_batch = 32
@@ -367,7 +373,26 @@ def main():
             f"{count} img/rank in micro-batches of {', '.join(str(micro[r]) for r in resolutions)}")
     losses = []
     for i in range(args.warmup):
-        loss = one_step()
+        retry = False
+        try:
+            loss = one_step()
+        except torch.OutOfMemoryError:
+            # the automatic micro-batch (128 on a 288 GB device: peak 245 GiB) did not fit on this box: fall back to 64 once --
+            # only with ONE rank (a lone rank's fallback would desynchronise DDP's collectives)
+            if not (auto_mb and i == 0 and world == 1 and args.micro_batch > 64):
+                raise
+            retry = True
+        if retry:       # (outside the handler: the traceback kept the failed pass's tensors alive)
+            import gc
+            log(f"micro-batch {args.micro_batch} ran out of memory: falling back to 64")
+            args.micro_batch = 64
+            micro = {r: max(1, 64 * 256 * 256 // (r * r)) for r in resolutions}
+            opt.zero_grad(set_to_none=True)
+            opt_step[0] = 0
+            gc.collect()
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats(dev)
+            loss = one_step()
         losses.append(loss)
         if rank == 0:
             torch.cuda.synchronize()
