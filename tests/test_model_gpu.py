@@ -89,6 +89,66 @@ def test_transvae_block(golden_dir):
     run_module(TransVAEBlock(dim=128), "tvblock.", (2, 128, 8, 8), golden(golden_dir, "mod_tvblock.npz"))
 
 
+def test_convffn_collapsed_tail_at_a_large_token_count_against_the_reference_order_of_operations():
+    """The Conv-FFN branch as the model runs it at scale (fused.ConvFFNBranchFn: collapsed tail, both two-source GEMMs active:
+    65 536 tokens take the 256-row tiles), forward and backward, against the REFERENCE's order of operations computed in fp32
+    with plain torch ops on the CPU on the same bf16-rounded input (R/transvae/modules/conv.py:69-105: u = u + conv(...), then proj_out), and
+    against the same Function with the two-source launches switched off (two GEMMs + second-residual epilogue, the path the
+    small golden tests exercise).  dim 384 = stage 2 of Large; bf16 tier 1e-2 / 3e-2; the two launch forms agree to 3e-3."""
+    from transvae.hip import fused, ops
+    from transvae.modules.conv import ConvFFN
+    dim, B, H, W = 384, 16, 64, 64
+    T = B * H * W
+    ffn = ConvFFN(dim)
+    sd = {k: filler.fill_tensor("ffnbig." + k, v.shape) for k, v in ffn.state_dict().items()}
+    ffn.load_state_dict(sd)
+    ffn = ffn.to(DEV)
+    rms_w = (1.0 + 0.1 * filler.randn_input("ffnbig.rms", (dim,))).to(DEV).requires_grad_(True)
+    t0 = filler.randn_input("ffnbig.t", (T, dim)).to(torch.bfloat16)
+    g0 = filler.randn_input("ffnbig.g", (T, dim)).to(torch.bfloat16)
+
+    def run(two_source: bool):
+        saved = ops.gemm_rows2
+        if not two_source:
+            ops.gemm_rows2 = lambda *a, **k: None
+        try:
+            for p in list(ffn.parameters()) + [rms_w]:
+                p.grad = None
+            t = t0.to(DEV).requires_grad_(True)
+            out = ffn.forward_tokens(t, B, H, W, rms_w, 1e-6)
+            out.backward(g0.to(DEV))
+            torch.cuda.synchronize()
+            return (out.detach().float().cpu(), t.grad.detach().float().cpu(),
+                    {k: p.grad.detach().float().cpu() for k, p in list(ffn.named_parameters()) + [("rms", rms_w)]})
+        finally:
+            ops.gemm_rows2 = saved
+    o2, dt2, g2 = run(True)
+    o1, dt1, g1 = run(False)
+    assert l2rel(o2, o1) < 3e-3 and l2rel(dt2, dt1) < 3e-3, (l2rel(o2, o1), l2rel(dt2, dt1))
+    for k in g1:
+        assert l2rel(g2[k], g1[k]) < 3e-3, (k, l2rel(g2[k], g1[k]))
+    # the reference's order of operations in fp32 (on the CPU): RMSNorm -> proj_in -> GELU -> conv chain -> u + c -> proj_out, + t
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    P = {k: v.clone().float().requires_grad_(True) for k, v in sd.items()}
+    rw = rms_w.detach().cpu().float().requires_grad_(True)
+    t = t0.float().requires_grad_(True)
+    r = t / torch.sqrt(t.pow(2).mean(1, keepdim=True) + 1e-6) * rw
+    u = torch.nn.functional.gelu(r @ P["proj_in.weight"].t() + P["proj_in.bias"])
+    hid, mid = u.shape[1], dim
+    c = torch.nn.functional.gelu(u @ P["conv.0.weight"].view(mid, hid).t() + P["conv.0.bias"])
+    c = c.view(B, H, W, mid).permute(0, 3, 1, 2)
+    c = torch.nn.functional.gelu(torch.nn.functional.conv2d(c, P["conv.2.weight"], P["conv.2.bias"], padding=1))
+    c = c.permute(0, 2, 3, 1).reshape(T, mid)
+    u2 = u + c @ P["conv.4.weight"].view(hid, mid).t() + P["conv.4.bias"]
+    ref = t + u2 @ P["proj_out.weight"].t() + P["proj_out.bias"]
+    ref.backward(g0.float())
+    e_out, e_dt = l2rel(o2, ref.detach().float()), l2rel(dt2, t.grad.float())
+    worst = max((l2rel(g2[k], P[k].grad.float()), k) for k in P)
+    e_rms = l2rel(g2["rms"], rw.grad.float())
+    print("Conv-FFN at 65 536 tokens, collapsed tail vs the reference's order in fp32: out", e_out, "dt", e_dt, "worst parameter gradient", worst, "rms weight", e_rms)
+    assert e_out < TOL_OUT and e_dt < TOL_GRAD and worst[0] < TOL_GRAD and e_rms < TOL_GRAD, (e_out, e_dt, worst, e_rms)
+
+
 def test_downsample(golden_dir):
     from transvae.modules.upsample import Downsample
     run_module(Downsample(64, 128), "down.", (2, 64, 16, 16), golden(golden_dir, "mod_down.npz"))
