@@ -22,9 +22,16 @@ non-finite or any step was skipped prints no metric line and exits non-zero.
 documented, never implemented there); every rank runs the same resolution in a given step.
 
 Rank 0 prints ONE JSON line.  `roofline` times the dominant kernel (the 192->192 3x3 implicit-GEMM
-convolution of the 256x256 stages, tv_igemm_nt) live with HIP events on the launch stream;
-`cpu_baseline` times the fp32 CPU oracle (a port of the reference path, pinned to it by golden
-vectors) on a bounded sample: ONE image through the same train step on the host cores.
+convolution of the 256x256 stages, tv_igemm_nt; one launch = 64 images) live with HIP events on the launch
+stream, `roofline.also` its weight gradient and the largest linear layer; `traffic` comes from the committed PMC
+summaries under profiles/ (labelled: not measured inside the run).  `cpu_baseline` times the fp32 CPU oracle (a
+port of the reference path, pinned to it by golden vectors) on a bounded sample: a micro-batch of 2
+images through the same train step, one untimed warm-up step + two timed steps, thread and core counts stated.
+
+Micro-batch: 128 images on a 288 GB device (peak 245 GiB; falls back to 64 if the first step runs out of memory),
+64 otherwise; `config.micro_batch` says which ran.  Started by torch.distributed.run (also with ONE rank) the step
+goes through DistributedDataParallel over RCCL (`config.dist_backend`).  TV_* tuning variables of the library
+are refused unless --allow-tuning-env (then listed in `config.tuning_env`).
 """
 from __future__ import annotations
 
