@@ -470,7 +470,7 @@ def main():
             out["mfma_roofline_frac"] = round(ips * gf / 1e3 / world / PEAK_BF16_TFLOPS, 4)
             out["flop_accounting"] = ("model_tflops = images/s x the REFERENCE's algorithmic FLOPs per image (SURVEY 8d: 2 MAC, 3x forward); the path "
                                       "executes fewer: exact reformulations (Conv-FFN tail on the composite W_out W3: -283 GF per Large image; "
-                                      "polyphase up-convolution and parity data gradient: 4 / 16 taps for 9 / 36) -- DESIGN 4, 4.6")
+                                      "polyphase up-convolutions: 4 taps for 9, ~-180 GF) -- DESIGN 4, 4.6")
         log("timing the dominant kernel")
         kmb = min(args.micro_batch, count, 64)     # ONE launch: 64 images (a 128-image micro-batch's 3.2 GB tensors go out as two launches of 64)
         out["roofline"] = time_dominant_kernel(kmb, 256, dev)
